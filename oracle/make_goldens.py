@@ -1,0 +1,355 @@
+"""
+Golden-fixture generator -- runs ONLY in the development container.
+
+Imports the real reference (marvinli00/genie2 mounted read-only at
+/root/reference) and drives its own modules -- `Denoiser`,
+`compute_frenet_frames`, `get_betas`, `sinusoidal_encoding`, `quat_to_rot`,
+`rot_to_quat`, `UnconditionalSampler._sample`, `save_np_features_to_pdb` --
+on seeded inputs, checks the restatement in `oracle/genie_oracle.py` against
+them, and writes the inputs + expected outputs as small `.npz` fixtures under
+`tests/golden/`.  Only data is written: no reference source travels.
+
+    python oracle/make_goldens.py            # regenerate every fixture
+
+The reference's Lightning-bound `Genie`/`DDPM` classes are not importable here
+(no pytorch_lightning); `_Shim` below supplies the handful of attributes
+`BaseSampler` reads (sampler/base.py:27-34, 236-270), deriving the schedule
+with the reference's own `get_betas` exactly as diffusion/ddpm.py:40-66 does.
+"""
+import hashlib
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get('GENIE_REFERENCE', '/root/reference')
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+from oracle import genie_oracle as O  # noqa: E402
+
+from genie.config import Config  # noqa: E402  (reference)
+from genie.model.model import Denoiser  # noqa: E402
+from genie.diffusion.schedule import get_betas  # noqa: E402
+from genie.utils.affine_utils import T, quat_to_rot, rot_to_quat  # noqa: E402
+from genie.utils.geo_utils import compute_frenet_frames  # noqa: E402
+from genie.utils.encoding import sinusoidal_encoding  # noqa: E402
+from genie.utils import feat_utils  # noqa: E402
+from genie.sampler.unconditional import UnconditionalSampler  # noqa: E402
+import genie.model.pair_feature_net as ref_pfn  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+
+
+def ref_config(n_timestep=1000):
+    cfg = Config(os.path.join(REF, 'results', 'base', 'configuration'))
+    cfg.diffusion['n_timestep'] = n_timestep
+    return cfg
+
+
+def ref_denoiser(cfg, sd):
+    m = Denoiser(**cfg.model, n_timestep=cfg.diffusion['n_timestep'],
+                 max_n_res=cfg.io['max_n_res'], max_n_chain=cfg.io['max_n_chain']).eval()
+    m.load_state_dict(sd, strict=True)
+    return m
+
+
+class _Shim:
+    """Lightning-free stand-in for genie.diffusion.genie.Genie."""
+
+    def __init__(self, cfg, denoiser):
+        self.config = cfg
+        self.device = torch.device('cpu')
+        self.model = denoiser
+
+    def setup_schedule(self):
+        self.betas = get_betas(self.config.diffusion['n_timestep'], self.config.diffusion['schedule'])
+        self.alphas = 1. - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, 0)
+        self.sqrt_betas = torch.sqrt(self.betas)
+        self.sqrt_alphas = torch.sqrt(self.alphas)
+        self.sqrt_one_minus_alphas_cumprod = torch.sqrt(1. - self.alphas_cumprod)
+
+
+def sha(t):
+    return hashlib.sha256(t.detach().cpu().numpy().tobytes()).hexdigest()
+
+
+def feats_to_np(f):
+    return {('f_' + k): v.numpy() for k, v in f.items()}
+
+
+def maxdiff(a, b):
+    return float((a - b).abs().max())
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **{k: (v.numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()})
+    print(f'  wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)')
+
+
+# ------------------------------------------------------------------ KATs
+
+def gen_schedule():
+    out = {}
+    for Tn in (100, 1000):
+        b = get_betas(Tn, 'cosine')
+        mine = O.cosine_beta_schedule(Tn)
+        assert torch.equal(b, mine), 'schedule restatement differs'
+        out[f'betas_{Tn}'] = b
+    save('schedule', **out)
+
+
+def gen_encoding():
+    out = {}
+    for nm, (vmax, N, D) in dict(pos=(256, 256, 256), chain=(4, 1, 64), t1000=(1001, 1000, 512),
+                                 t100=(101, 100, 512)).items():
+        v = torch.arange(vmax, dtype=torch.int32)
+        e = sinusoidal_encoding(v, N, D)
+        mine = O.sinusoidal_encoding(v, N, D)
+        assert torch.equal(e, mine), 'encoding restatement differs'
+        # tables are large; store a strided sample plus a checksum of the whole
+        out[nm + '_rows'] = np.array([0, 1, 2, vmax // 2, vmax - 1])
+        out[nm + '_vals'] = e[out[nm + '_rows']]
+        out[nm + '_sum'] = e.double().sum()
+        out[nm + '_abs_sum'] = e.double().abs().sum()
+    save('encoding', **out)
+
+
+def gen_geometry():
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    # frenet: ragged, multi-chain, B != 3 (torch.cross without dim, see oracle docstring)
+    B, N = 4, 24
+    coords = 3.0 * torch.randn(B, N, 3, generator=g)
+    mask = torch.zeros(B, N, dtype=torch.int32)
+    lengths = [24, 17, 9, 5]
+    chains = torch.zeros(B, N, dtype=torch.int32)
+    for b, L in enumerate(lengths):
+        mask[b, :L] = 1
+    chains[1, 8:17] = 1          # two chains 8 + 9
+    chains[2, 3:6] = 1
+    chains[2, 6:9] = 2           # three chains 3 + 3 + 3
+    rots = compute_frenet_frames(coords, chains, mask)
+    mine = O.compute_frenet_frames(coords, chains, mask)
+    assert maxdiff(rots, mine) == 0.0, 'frenet restatement differs'
+    det = torch.linalg.det(rots[0, :24])
+    assert torch.allclose(det, -torch.ones_like(det), atol=1e-4), 'expected improper frames'
+    out.update(frenet_coords=coords, frenet_mask=mask, frenet_chains=chains, frenet_rots=rots)
+    # quat_to_rot
+    q = torch.randn(64, 4, generator=g)
+    q = q / q.norm(dim=-1, keepdim=True)
+    r = quat_to_rot(q)
+    assert maxdiff(r, O.quat_to_rot(q)) < 1e-6
+    out.update(q2r_q=q, q2r_r=r)
+    # rot_to_quat on products of frenet frames (R_j . R_i, proper)
+    fr = rots[0]
+    rr = torch.matmul(fr.unsqueeze(0), fr.unsqueeze(1))
+    qe = rot_to_quat(rr)
+    qc = O.rot_to_quat_closed(rr)
+    codes = O.quat_sign_codes(qe)
+    qa = O.apply_sign_codes(qc, codes)
+    print('  rot_to_quat eigh vs closed (sign aligned):', maxdiff(qe, qa))
+    assert maxdiff(qe, qa) < 2e-4
+    out.update(r2q_r=rr, r2q_q=qe, r2q_codes=codes)
+    save('geometry', **out)
+
+
+def gen_pdb():
+    f = feat_utils.create_empty_np_features([7])
+    g = np.random.RandomState(3)
+    f['atom_positions'] = g.randn(7, 3) * 10
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, 'x.pdb')
+        feat_utils.save_np_features_to_pdb(f, p)
+        data = open(p, 'rb').read()
+    save('pdb_writer', atom_positions=f['atom_positions'], pdb_bytes=np.frombuffer(data, dtype=np.uint8))
+
+
+# ------------------------------------------------------------------ single calls
+
+def run_ref_call(model, rots, trans, ts, feats, record):
+    """One reference Denoiser.forward with hooks for stage taps + eigh signs."""
+    taps = {}
+    orig = ref_pfn.rot_to_quat
+
+    def rec_q(r):
+        q = orig(r)
+        record.append(q)
+        return q
+
+    ref_pfn.rot_to_quat = rec_q
+    hooks = [
+        model.pair_feature_net.register_forward_hook(lambda m, i, o: taps.__setitem__('p_init', o)),
+        model.pair_transform_net.net[0].register_forward_hook(lambda m, i, o: taps.__setitem__('p_after_layer0', o[0])),
+        model.pair_transform_net.net[0].tri_mul_out.register_forward_hook(lambda m, i, o: taps.__setitem__('trimul_out0', o)),
+        model.structure_net.net[0].ipa.register_forward_hook(lambda m, i, o: taps.__setitem__('ipa_out0', o)),
+    ]
+    try:
+        with torch.no_grad():
+            out = model(T(rots, trans), ts, feats)
+    finally:
+        ref_pfn.rot_to_quat = orig
+        for h in hooks:
+            h.remove()
+    return out, taps
+
+
+def case_inputs(name, g):
+    """(features, trans, timestep) for each single-call case."""
+    if name == 'uncond_n16_b1_t1000':
+        f = O.empty_features([16]); t = 1000
+    elif name == 'uncond_n32_b2_t500':
+        f = O.empty_features([32, 32]); t = 500
+    elif name == 'ragged_n50_b2_t1':
+        f = O.empty_features([50, 37]); t = 1
+    elif name == 'twochain_n32_b1_t777':
+        f = O.empty_features([32], chains_per_sample=[[20, 12]]); t = 777
+    elif name == 'motif_n40_b2_t300':
+        f = O.empty_features([40, 33])
+        seqs, coords = feat_utils.parse_pdb(os.path.join(REF, '6E6R_long_motif.pdb'))
+        ca = torch.tensor(coords[0][:10], dtype=torch.float32)
+        ca = ca - ca.mean(0, keepdim=True)
+        O.add_motif(f, 0, ca, list(range(12, 22)), aatype_idx=torch.tensor(seqs[0][:10]))
+        O.add_motif(f, 1, ca[:6], [3, 4, 5, 20, 21, 22])
+        t = 300
+    else:
+        raise KeyError(name)
+    B, N = f['residue_mask'].shape
+    trans = 2.5 * torch.randn(B, N, 3, generator=g)
+    return f, trans, t
+
+
+def gen_single_calls(sd):
+    cfg = ref_config(1000)
+    model = ref_denoiser(cfg, sd)
+    dims = dict(O.BASE_DIMS)
+    g = torch.Generator().manual_seed(11)
+    pick = torch.Generator().manual_seed(5)
+    for name in ('uncond_n16_b1_t1000', 'uncond_n32_b2_t500', 'ragged_n50_b2_t1',
+                 'twochain_n32_b1_t777', 'motif_n40_b2_t300'):
+        print(name)
+        f, trans, t = case_inputs(name, g)
+        B, N = f['residue_mask'].shape
+        fr = O.prepare_features(f)
+        rots = compute_frenet_frames(trans, fr['chain_index'], fr['residue_mask'])
+        ts = torch.full((B,), t, dtype=torch.int32)
+        rec = []
+        out, taps = run_ref_call(model, rots, trans, ts, fr, rec)
+        codes = O.quat_sign_codes(rec[0])
+
+        # restatement check, both quaternion modes
+        o_e = O.denoiser_forward(sd, dims, rots, trans, ts, f, 'eigh')
+        o_c = O.denoiser_forward(sd, dims, rots, trans, ts, f, 'closed', codes)
+        m3 = fr['residue_mask'].unsqueeze(-1).float()
+        zs = float(out['z'].abs().max())
+        print(f'  |z|max {zs:.3f}  oracle(eigh) dz {maxdiff(out["z"] * m3, o_e["z"] * m3):.2e}'
+              f'  oracle(closed+codes) dz {maxdiff(out["z"] * m3, o_c["z"] * m3):.2e}'
+              f'  ds {maxdiff(out["s"], o_e["s"]):.2e}  dp {maxdiff(out["p"], o_e["p"]):.2e}')
+        assert maxdiff(out['z'] * m3, o_c['z'] * m3) <= 1e-4 * max(1.0, zs)
+        assert maxdiff(out['p'], o_c['p']) <= 2e-4 * max(1.0, float(out['p'].abs().max()))
+
+        # sampled pair entries (fixed index set) to keep the fixture small
+        n_s = 256
+        idx = torch.stack([torch.randint(0, B, (n_s,), generator=pick),
+                           torch.randint(0, N, (n_s,), generator=pick),
+                           torch.randint(0, N, (n_s,), generator=pick)], dim=1)
+
+        def samp(p):
+            return p[idx[:, 0], idx[:, 1], idx[:, 2]]
+
+        save('call_' + name,
+             timestep=t, trans=trans, rots=rots, quat_codes=codes,
+             z=out['z'], s=out['s'], states=out['states'][[1, -1]],
+             rots_out=out['ts'].rots, trans_out=out['ts'].trans,
+             p_idx=idx, p_final_samples=samp(out['p']), p_init_samples=samp(taps['p_init']),
+             p_layer0_samples=samp(taps['p_after_layer0']), trimul_out0_samples=samp(taps['trimul_out0']),
+             p_final_abs_mean=out['p'].abs().mean(), p_final_abs_max=out['p'].abs().max(),
+             ipa_out0=taps['ipa_out0'],
+             **feats_to_np(f))
+
+
+# ------------------------------------------------------------------ trajectory
+
+def gen_trajectory(sd):
+    """Config 1: N=50, T=100, B=1, scale 0.6 through the reference's real
+    UnconditionalSampler._sample (sampler/base.py:169-289)."""
+    Tn, N, B, scale, seed = 100, 50, 1, 0.6, 42
+    cfg = ref_config(Tn)
+    model = ref_denoiser(cfg, sd)
+    shim = _Shim(cfg, model)
+    sampler = UnconditionalSampler(shim)
+
+    torch.manual_seed(seed)
+    noise = torch.stack([torch.randn(B, N, 3) for _ in range(Tn)])   # draw order of base.py:227,269
+
+    rec, traj = [], []
+    orig_q = ref_pfn.rot_to_quat
+
+    def rec_q(r):
+        q = orig_q(r)
+        rec.append(O.quat_sign_codes(q))
+        return q
+
+    ref_pfn.rot_to_quat = rec_q
+    # record x_t after every step through the frenet call at the end of each iteration
+    import genie.sampler.base as ref_base
+    orig_f = ref_base.compute_frenet_frames
+    ref_base.compute_frenet_frames = lambda c, ch, m: (traj.append(c.clone()) or orig_f(c, ch, m))
+    torch.manual_seed(seed)
+    t0 = time.time()
+    try:
+        out = sampler._sample(dict(length=N, scale=scale, num_samples=B, outdir='.', prefix='x', offset=0))
+    finally:
+        ref_pfn.rot_to_quat = orig_q
+        ref_base.compute_frenet_frames = orig_f
+    dt = time.time() - t0
+    print(f'  reference _sample N={N} T={Tn}: {dt:.1f}s = {Tn / dt:.2f} steps/s ({torch.get_num_threads()} threads)')
+    final = torch.tensor(out[0]['atom_positions'], dtype=torch.float32)[None]
+    assert torch.equal(traj[0], noise[0]), 'noise replay mismatch'
+    traj = torch.stack(traj[1:])                       # [T, B, N, 3] state after each step
+    codes = torch.stack(rec)                           # [T, B, N, N]
+    assert codes.shape[0] == Tn
+
+    # restatement check with the recorded signs
+    dims = dict(O.BASE_DIMS, n_timestep=Tn)
+    f = O.empty_features([N] * B)
+    mine, _, _ = O.sample_loop(sd, dims, f, noise, scale, 'closed', codes)
+    rms = float(final.pow(2).mean().sqrt())
+    print(f'  oracle(closed+codes) vs reference: max|dCa| {maxdiff(mine, final):.2e} at coordinate RMS {rms:.2f}')
+    assert maxdiff(mine, final) <= 1e-4 * rms
+    save('trajectory_n50_t100', noise=noise, quat_codes=codes, final=final, every10=traj[9::10],
+         scale=scale, seed=seed, ref_steps_per_s=Tn / dt, ref_threads=torch.get_num_threads())
+
+
+def main():
+    torch.manual_seed(0)
+    print('weights (synthetic recipe, seed 0)')
+    sd = O.synthetic_state_dict(O.BASE_DIMS, seed=0)
+    # key/shape layout must equal the reference's own state_dict
+    cfg = ref_config()
+    ref_sd = ref_denoiser(cfg, sd).state_dict()
+    assert list(ref_sd.keys()) == [k for k, _ in O.state_dict_template(O.BASE_DIMS)]
+    h = hashlib.sha256()
+    for k in sd:
+        h.update(sd[k].numpy().tobytes())
+    save('weights_recipe', sha256=np.frombuffer(h.digest(), dtype=np.uint8),
+         n_params=sum(v.numel() for v in sd.values()),
+         probe=sd['structure_net.net.7.ipa.linear_out.weight'][:4, :8])
+    print('schedule'); gen_schedule()
+    print('encoding'); gen_encoding()
+    print('geometry'); gen_geometry()
+    print('pdb'); gen_pdb()
+    gen_single_calls(sd)
+    print('trajectory'); gen_trajectory(sd)
+
+
+if __name__ == '__main__':
+    main()
