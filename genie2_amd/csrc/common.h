@@ -1,0 +1,211 @@
+// Shared declarations for libgenie_hip.so (gfx950 / CDNA4 only).
+//
+// GEMM convention used by every MFMA kernel here
+// ------------------------------------------------
+// v_mfma_f32_32x32x2_f32 (exact fp32, one fmaf chain per output):
+//   A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31],
+//   D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31], r = 0..15.
+// Operands are consumed 8 k-values at a time as one float4 per lane:
+//   frag.e = X[idx = lane&31][k = 8*kb + 4*(lane>>5) + e],  e = 0..3
+// and MFMA e pairs k = 8kb+e (lanes < 32) with k = 8kb+4+e (lanes >= 32).
+// Weights are repacked once on the host into that order ("fragment-major"):
+//   Wp[((nb*KB + kb)*64 + lane)*4 + e] = W[32nb + (lane&31)][8kb + 4(lane>>5) + e]
+// so a wave fetches a whole fragment with ONE coalesced 1-KiB global_load_dwordx4
+// (L2 resident: the largest weight is 3.2 MB) and needs no LDS staging or
+// barrier for weights.  Activations are staged per tile in LDS, K-contiguous
+// with a +4 float row pad, which makes the float4 fragment read
+// (ds_read_b128, 16-lane groups, bank = (addr/4) % 64) conflict free.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/genie_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define GENIE_LN_EPS 1e-5f
+
+// ---------------------------------------------------------------- device helpers
+#ifdef __HIPCC__
+
+__device__ __forceinline__ f32x16 mfma_8k(const float4 a, const float4 b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, c, 0, 0, 0);
+    return c;
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// row index inside a 32x32 accumulator tile held in register r by this lane
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// packed-weight fragment (see header comment)
+__device__ __forceinline__ float4 wfrag(const float* __restrict__ wp, int KB, int nb, int kb, int lane) {
+    return *reinterpret_cast<const float4*>(wp + ((size_t)(nb * KB + kb) * 64 + lane) * 4);
+}
+
+// K-contiguous LDS tile fragment: rows r0..r0+31, k-block kb
+__device__ __forceinline__ float4 lfrag(const float* lds, int ld, int r0, int kb, int lane) {
+    return *reinterpret_cast<const float4*>(lds + (r0 + (lane & 31)) * ld + kb * 8 + 4 * (lane >> 5));
+}
+
+// M-contiguous LDS tile ([k][ld], idx contiguous): same fragment, 4 scalar reads
+__device__ __forceinline__ float4 lfrag_t(const float* lds, int ld, int i0, int kb, int lane) {
+    const float* p = lds + (kb * 8 + 4 * (lane >> 5)) * ld + i0 + (lane & 31);
+    return make_float4(p[0], p[ld], p[2 * ld], p[3 * ld]);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// In-place LayerNorm of a [rows][ld] LDS tile with `C` channels (C = 128):
+// 4 threads per row (256 threads <-> 64 rows).  Two-pass mean / variance.
+__device__ __forceinline__ void ln_rows_128(float* tile, int ld, const float* __restrict__ gamma,
+                                            const float* __restrict__ beta, int tid) {
+    const int row = tid >> 2, part = tid & 3;
+    float* p = tile + row * ld + part * 32;
+    float v[32];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        float4 t = *reinterpret_cast<float4*>(p + 4 * q);
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) s += v[q];
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+    const float mean = s * (1.0f / 128.0f);
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) { float d = v[q] - mean; ss += d * d; }
+    ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2);
+    const float rstd = 1.0f / sqrtf(ss * (1.0f / 128.0f) + GENIE_LN_EPS);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = part * 32 + 4 * q;
+        float4 g = *reinterpret_cast<const float4*>(gamma + c);
+        float4 b = *reinterpret_cast<const float4*>(beta + c);
+        float4 o;
+        o.x = (v[4 * q] - mean) * rstd * g.x + b.x;
+        o.y = (v[4 * q + 1] - mean) * rstd * g.y + b.y;
+        o.z = (v[4 * q + 2] - mean) * rstd * g.z + b.z;
+        o.w = (v[4 * q + 3] - mean) * rstd * g.w + b.w;
+        *reinterpret_cast<float4*>(p + 4 * q) = o;
+    }
+}
+
+#endif  // __HIPCC__
+
+// ---------------------------------------------------------------- host side
+
+enum KernelClass {
+    KC_SINGLE_INPUT = 0, KC_GEMM_ROWS, KC_LAYERNORM, KC_PAIR_STATIC, KC_PAIR_INIT,
+    KC_TRIMUL_PROJ, KC_TRIMUL_CONTRACT, KC_TRIMUL_OUT, KC_PAIR_TRANSITION,
+    KC_IPA_BIAS, KC_IPA_PREP, KC_IPA_ATTN, KC_BB_UPDATE, KC_P_SAMPLE, KC_MISC, KC_COUNT
+};
+
+struct TriMulW {
+    float *proj_w;            // packed [512][128]: a_p | b_p | a_g | b_g
+    float *proj_b;            // [512] same order
+    float *g_w, *g_b;         // packed [128][128], [128]
+    float *z_w, *z_b;         // packed [c_p][c_hidden]
+    float *ln_in_g, *ln_in_b, *ln_out_g, *ln_out_b;
+};
+struct PairLayerW {
+    TriMulW out, in;
+    float *pt_ln_g, *pt_ln_b, *pt_w1, *pt_b1, *pt_w2, *pt_b2;   // w1 packed [512][128], w2 packed [128][512]
+};
+struct StructLayerW {
+    float *proj_w, *proj_b;       // packed [1152][384]: q | kv | q_pts | kv_pts
+    float *head_w;                // [H] raw head_weights
+    float *out_w, *out_b;         // packed [384][2112]
+    float *ln_ipa_g, *ln_ipa_b;
+    float *t1_w, *t1_b, *t2_w, *t2_b, *t3_w, *t3_b;
+    float *ln_tr_g, *ln_tr_b;
+    float *bb_w, *bb_b;           // raw [6][384], [6]
+};
+
+struct genie_ctx {
+    genie_dims_t d;
+    int device;
+    char err[512];
+
+    // weights
+    bool have_weights;
+    float* wdev;                  // one device allocation holding everything below
+    size_t wdev_floats;
+    float *single_w;              // packed [384][856]
+    float *pij_w;                 // packed [256][384]: linear_s_p_i | linear_s_p_j
+    float *relpos_t;              // [67][128] transposed raw
+    float *templ_w;               // packed [128][48]
+    float *motif_w;               // packed [128][40]
+    float *ipa_bias_w, *ipa_bias_b;   // packed [ceil32(L*H)][128], [L*H]
+    PairLayerW* pair;             // host arrays of device pointers
+    StructLayerW* st;
+
+    // tables
+    bool have_tables;
+    float *pos_tab, *chain_tab, *t_tab, *sched;
+    int n_pos, n_chain;
+    float* sched_host;            // [4][T+1]
+
+    // bound batch
+    int B, N, NP;
+    bool have_feats, has_motif;
+    int32_t *f_aatype, *f_rmask, *f_ridx, *f_cidx;
+    float *f_pos;
+    uint8_t *f_fsm, *f_fstm, *f_ifm;
+    float *rmaskf;                // [B,N] residue mask as float
+
+    // workspace (one allocation, carved)
+    void* ws; size_t ws_bytes;
+    float *p, *acm, *bcm, *xcm, *pstatic, *ipa_bias;
+    float *xsingle, *s0, *s, *s1, *s2, *h1, *h2, *pij, *proj, *cat;
+    float *kT, *v, *qp, *kpT, *vp;
+    float *rots_w, *trans_w;      // working frames
+    int32_t* tsteps;              // [B] uniform timestep buffer for the loop
+    float *loop_z;                // [B,N,3]
+
+    // profiling
+    bool prof;
+    struct ProfRec { int cls; hipEvent_t a, b; };
+    ProfRec* prof_recs; int prof_n, prof_cap;
+    double prof_ms[KC_COUNT]; int64_t prof_cnt[KC_COUNT];
+};
+
+// launchers (each enqueues on `st`, no sync)
+void launch_single_input(genie_ctx* h, hipStream_t st, const int32_t* timesteps);
+void launch_gemm_rows(genie_ctx* h, hipStream_t st, const float* A, int lda, int M, int K,
+                      const float* Wp, int Nout, const float* bias, const float* res, int ldr,
+                      const float* rowmask, int relu, float* out, int ldo);
+void launch_layernorm_rows(genie_ctx* h, hipStream_t st, const float* in, float* out, int M, int C,
+                           const float* g, const float* b);
+void launch_pair_static(genie_ctx* h, hipStream_t st);
+void launch_pair_init(genie_ctx* h, hipStream_t st, const float* trans, const float* rots,
+                      const int8_t* codes);
+void launch_trimul(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgoing);
+void launch_pair_transition(genie_ctx* h, hipStream_t st, const PairLayerW& w);
+void launch_ipa_bias(genie_ctx* h, hipStream_t st);
+void launch_ipa_prep(genie_ctx* h, hipStream_t st);
+void launch_ipa_attn(genie_ctx* h, hipStream_t st, int layer, const float* head_w);
+void launch_bb_update(genie_ctx* h, hipStream_t st, const StructLayerW& w, const float* trans_in,
+                      float* z_out);
+void launch_frenet(genie_ctx* h, hipStream_t st, int mode, int step, float scale, float* trans,
+                   float* rots, const float* z, const float* eps);
+void launch_fill_i32(genie_ctx* h, hipStream_t st, int32_t* p, int n, int v);
+
+// profiling hooks used by the launchers
+void prof_begin(genie_ctx* h, hipStream_t st, int cls);
+void prof_end(genie_ctx* h, hipStream_t st);
+
+struct ProfScope {
+    genie_ctx* h; hipStream_t st;
+    ProfScope(genie_ctx* h_, hipStream_t st_, int cls) : h(h_), st(st_) { if (h->prof) prof_begin(h, st, cls); }
+    ~ProfScope() { if (h->prof) prof_end(h, st); }
+};

@@ -1,0 +1,523 @@
+// Host side of libgenie_hip.so: handle, weight repacking, workspace, the
+// per-step launch sequence and the device-resident reverse loop.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+void pair_kernels_init();
+void single_kernels_init(const genie_dims_t& d, int n_max);
+void launch_scale_copy(genie_ctx* h, hipStream_t st, const float* in, float* out, int n, float s);
+size_t ipa_attn_lds(const genie_dims_t& d, int N);
+
+static char g_create_err[512] = "";
+
+#define SET_ERR(h, ...) do { snprintf((h)->err, sizeof((h)->err), __VA_ARGS__); } while (0)
+#define HIP_TRY(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    SET_ERR(h, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return GENIE_E_HIP; } } while (0)
+
+static const char* kKernelNames[KC_COUNT] = {
+    "single_input", "gemm_rows", "layernorm_rows", "pair_static", "pair_init", "trimul_proj", "trimul_contract",
+    "trimul_out", "pair_transition", "ipa_bias", "ipa_prep", "ipa_attn", "bb_update", "p_sample_frenet", "misc"};
+
+// ------------------------------------------------------------------ profiling
+void prof_begin(genie_ctx* h, hipStream_t st, int cls) {
+    if (h->prof_n == h->prof_cap) {
+        const int nc = h->prof_cap ? h->prof_cap * 2 : 1024;
+        h->prof_recs = (genie_ctx::ProfRec*)realloc(h->prof_recs, nc * sizeof(genie_ctx::ProfRec));
+        h->prof_cap = nc;
+    }
+    genie_ctx::ProfRec& r = h->prof_recs[h->prof_n];
+    r.cls = cls;
+    hipEventCreate(&r.a);
+    hipEventCreate(&r.b);
+    hipEventRecord(r.a, st);
+}
+void prof_end(genie_ctx* h, hipStream_t st) {
+    hipEventRecord(h->prof_recs[h->prof_n].b, st);
+    h->prof_n++;
+}
+
+// ------------------------------------------------------------------ dims
+static int single_in(const genie_dims_t& d) { return d.c_pos_emb + d.c_chain_emb + d.c_timestep_emb + 23; }
+static int ipa_proj_n(const genie_dims_t& d) {
+    return d.n_head_ipa * (3 * d.c_hidden_ipa + 3 * d.n_qk_point + 3 * (d.n_qk_point + d.n_v_point));
+}
+static int ipa_cat_n(const genie_dims_t& d) { return d.n_head_ipa * (d.c_p + d.c_hidden_ipa + 4 * d.n_v_point); }
+
+static const char* check_dims(const genie_dims_t& d) {
+    if (d.c_p != 128 || d.c_hidden_mul != 128) return "kernels are specialised for c_p == c_hidden_mul == 128";
+    if (d.c_s % 8 || d.c_s > 512) return "c_s must be a multiple of 8 and <= 512";
+    if (d.template_dist_n_bin > 40 || d.template_dist_n_bin < 1) return "template_dist_n_bin must be in [1, 40]";
+    if (d.n_head_ipa > 16) return "n_head_ipa must be <= 16";
+    if (d.pair_transition_n < 1 || d.n_timestep < 1 || d.relpos_k < 0) return "bad dims";
+    if (d.n_structure_layer < 1 || d.n_structure_block < 1 || d.n_pair_transform_layer < 0) return "bad layer counts";
+    if ((d.n_head_ipa * d.c_hidden_ipa) % 4 || ipa_cat_n(d) % 4 || ipa_proj_n(d) % 4) return "IPA widths must be multiples of 4";
+    return nullptr;
+}
+
+size_t genie_weight_count(const genie_dims_t* dp) {
+    const genie_dims_t& d = *dp;
+    size_t n = 0;
+    const size_t cs = d.c_s, cp = d.c_p, ch = d.c_hidden_mul;
+    n += cs * single_in(d);
+    n += 2 * cp * cs + cp * (2 * d.relpos_k + 3) + cp * (d.template_dist_n_bin + 6) + cp * (d.template_dist_n_bin + 2);
+    const size_t tm = 4 * (ch * cp + ch) + (cp * cp + cp) + (cp * ch + cp) + 2 * cp + 2 * ch;
+    const size_t pt = 2 * cp + (d.pair_transition_n * cp * cp + d.pair_transition_n * cp) + (cp * d.pair_transition_n * cp + cp);
+    n += (size_t)d.n_pair_transform_layer * (2 * tm + pt);
+    const size_t H = d.n_head_ipa, C = d.c_hidden_ipa, Pq = d.n_qk_point, Pv = d.n_v_point;
+    size_t sl = H;
+    sl += (H * C) * cs + H * C + (2 * H * C) * cs + 2 * H * C + (3 * H * Pq) * cs + 3 * H * Pq + (3 * H * (Pq + Pv)) * cs + 3 * H * (Pq + Pv);
+    sl += H * cp + H + cs * ipa_cat_n(d) + cs;
+    sl += 2 * cs + 3 * (cs * cs + cs) + 2 * cs + 6 * cs + 6;
+    n += (size_t)d.n_structure_layer * sl;
+    return n;
+}
+
+// ------------------------------------------------------------------ create / destroy
+int genie_create(const genie_dims_t* dims, int device, genie_handle_t* out) {
+    if (!dims || !out) { snprintf(g_create_err, sizeof g_create_err, "genie_create: null argument"); return GENIE_E_ARG; }
+    if (const char* m = check_dims(*dims)) { snprintf(g_create_err, sizeof g_create_err, "genie_create: %s", m); return GENIE_E_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        snprintf(g_create_err, sizeof g_create_err, "genie_create: no HIP device %d (found %d)", device, ndev);
+        return GENIE_E_HIP;
+    }
+    genie_ctx* h = new (std::nothrow) genie_ctx();
+    if (!h) return GENIE_E_NOMEM;
+    memset(h, 0, sizeof(*h));
+    h->d = *dims;
+    h->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete h; snprintf(g_create_err, sizeof g_create_err, "hipSetDevice failed"); return GENIE_E_HIP; }
+    h->pair = new PairLayerW[dims->n_pair_transform_layer > 0 ? dims->n_pair_transform_layer : 1]();
+    h->st = new StructLayerW[dims->n_structure_layer]();
+    pair_kernels_init();
+    *out = h;
+    return GENIE_OK;
+}
+
+static void free_batch(genie_ctx* h) {
+    if (h->ws) { hipFree(h->ws); h->ws = nullptr; h->ws_bytes = 0; }
+    h->have_feats = false;
+}
+
+void genie_destroy(genie_handle_t h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    free_batch(h);
+    if (h->wdev) hipFree(h->wdev);
+    if (h->pos_tab) hipFree(h->pos_tab);
+    free(h->sched_host);
+    for (int i = 0; i < h->prof_n; ++i) { hipEventDestroy(h->prof_recs[i].a); hipEventDestroy(h->prof_recs[i].b); }
+    free(h->prof_recs);
+    delete[] h->pair;
+    delete[] h->st;
+    delete h;
+}
+
+const char* genie_last_error(genie_handle_t h) { return h ? h->err : g_create_err; }
+size_t genie_workspace_bytes(genie_handle_t h) { return h ? h->ws_bytes : 0; }
+
+// ------------------------------------------------------------------ weights
+namespace {
+struct Img {
+    std::vector<float> data;
+    size_t add(size_t n) {            // 256-B aligned segment
+        const size_t off = (data.size() + 63) & ~(size_t)63;
+        data.resize(off + n, 0.f);
+        return off;
+    }
+    // raw copy
+    size_t raw(const float* src, size_t n) { const size_t o = add(n); memcpy(&data[o], src, n * sizeof(float)); return o; }
+    // fragment-major pack of W[rows][cols] (row-major, ld = cols)
+    size_t pack(const float* W, int rows, int cols) {
+        const int NB = (rows + 31) / 32, KB = (cols + 7) / 8;
+        const size_t o = add((size_t)NB * KB * 256);
+        float* p = &data[o];
+        for (int nb = 0; nb < NB; ++nb)
+            for (int kb = 0; kb < KB; ++kb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = nb * 32 + (lane & 31), k = kb * 8 + 4 * (lane >> 5) + e;
+                        p[(((size_t)nb * KB + kb) * 64 + lane) * 4 + e] = (r < rows && k < cols) ? W[(size_t)r * cols + k] : 0.f;
+                    }
+        return o;
+    }
+};
+struct Cur {
+    const float* p; size_t left;
+    const float* take(size_t n) { if (n > left) { left = 0; return nullptr; } const float* r = p; p += n; left -= n; return r; }
+};
+std::vector<float> vcat(std::initializer_list<std::pair<const float*, size_t>> parts) {
+    std::vector<float> v;
+    for (auto& pr : parts) v.insert(v.end(), pr.first, pr.first + pr.second);
+    return v;
+}
+}  // namespace
+
+int genie_load_weights(genie_handle_t h, const float* blob, size_t n_floats) {
+    if (!h || !blob) return GENIE_E_ARG;
+    const genie_dims_t& d = h->d;
+    if (n_floats != genie_weight_count(&d)) {
+        SET_ERR(h, "genie_load_weights: got %zu floats, dims need %zu", n_floats, genie_weight_count(&d));
+        return GENIE_E_ARG;
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t cs = d.c_s, cp = d.c_p, ch = d.c_hidden_mul;
+    Cur c{blob, n_floats};
+    Img img;
+    std::vector<std::pair<float**, size_t>> fix;     // (pointer slot, offset)
+    auto slot = [&](float** s, size_t off) { fix.push_back({s, off}); };
+
+    const int nsi = single_in(d);
+    slot(&h->single_w, img.pack(c.take(cs * nsi), (int)cs, nsi));
+    {
+        const float* wi = c.take(cp * cs);
+        const float* wj = c.take(cp * cs);
+        auto v = vcat({{wi, cp * cs}, {wj, cp * cs}});
+        slot(&h->pij_w, img.pack(v.data(), (int)(2 * cp), (int)cs));
+    }
+    {
+        const int nr = 2 * d.relpos_k + 3;
+        const float* w = c.take(cp * nr);
+        std::vector<float> t((size_t)nr * cp);
+        for (int o = 0; o < (int)cp; ++o) for (int k = 0; k < nr; ++k) t[(size_t)k * cp + o] = w[(size_t)o * nr + k];
+        slot(&h->relpos_t, img.raw(t.data(), t.size()));
+    }
+    {   // template: K padded to 48, motif: K padded to 40 (LDS tile widths of k_pair_init / k_pair_static)
+        const int kt = d.template_dist_n_bin + 6, km = d.template_dist_n_bin + 2;
+        const float* wt = c.take(cp * kt);
+        const float* wm = c.take(cp * km);
+        std::vector<float> t((size_t)cp * 48, 0.f), m((size_t)cp * 40, 0.f);
+        for (int o = 0; o < (int)cp; ++o) {
+            for (int k = 0; k < kt; ++k) t[(size_t)o * 48 + k] = wt[(size_t)o * kt + k];
+            for (int k = 0; k < km; ++k) m[(size_t)o * 40 + k] = wm[(size_t)o * km + k];
+        }
+        slot(&h->templ_w, img.pack(t.data(), (int)cp, 48));
+        slot(&h->motif_w, img.pack(m.data(), (int)cp, 40));
+    }
+    for (int l = 0; l < d.n_pair_transform_layer; ++l) {
+        PairLayerW& L = h->pair[l];
+        for (int dir = 0; dir < 2; ++dir) {
+            TriMulW& T = dir == 0 ? L.out : L.in;
+            const float* ap_w = c.take(ch * cp); const float* ap_b = c.take(ch);
+            const float* ag_w = c.take(ch * cp); const float* ag_b = c.take(ch);
+            const float* bp_w = c.take(ch * cp); const float* bp_b = c.take(ch);
+            const float* bg_w = c.take(ch * cp); const float* bg_b = c.take(ch);
+            const float* g_w = c.take(cp * cp);  const float* g_b = c.take(cp);
+            const float* z_w = c.take(cp * ch);  const float* z_b = c.take(cp);
+            const float* li_g = c.take(cp); const float* li_b = c.take(cp);
+            const float* lo_g = c.take(ch); const float* lo_b = c.take(ch);
+            auto w = vcat({{ap_w, ch * cp}, {bp_w, ch * cp}, {ag_w, ch * cp}, {bg_w, ch * cp}});
+            auto bb = vcat({{ap_b, ch}, {bp_b, ch}, {ag_b, ch}, {bg_b, ch}});
+            slot(&T.proj_w, img.pack(w.data(), (int)(4 * ch), (int)cp));
+            slot(&T.proj_b, img.raw(bb.data(), bb.size()));
+            slot(&T.g_w, img.pack(g_w, (int)cp, (int)cp)); slot(&T.g_b, img.raw(g_b, cp));
+            slot(&T.z_w, img.pack(z_w, (int)cp, (int)ch)); slot(&T.z_b, img.raw(z_b, cp));
+            slot(&T.ln_in_g, img.raw(li_g, cp)); slot(&T.ln_in_b, img.raw(li_b, cp));
+            slot(&T.ln_out_g, img.raw(lo_g, ch)); slot(&T.ln_out_b, img.raw(lo_b, ch));
+        }
+        const size_t nh = (size_t)d.pair_transition_n * cp;
+        const float* lg = c.take(cp); const float* lb = c.take(cp);
+        const float* w1 = c.take(nh * cp); const float* b1 = c.take(nh);
+        const float* w2 = c.take(cp * nh); const float* b2 = c.take(cp);
+        slot(&L.pt_ln_g, img.raw(lg, cp)); slot(&L.pt_ln_b, img.raw(lb, cp));
+        slot(&L.pt_w1, img.pack(w1, (int)nh, (int)cp)); slot(&L.pt_b1, img.raw(b1, nh));
+        slot(&L.pt_w2, img.pack(w2, (int)cp, (int)nh)); slot(&L.pt_b2, img.raw(b2, cp));
+    }
+    const size_t H = d.n_head_ipa, C = d.c_hidden_ipa, Pq = d.n_qk_point, Pv = d.n_v_point;
+    const size_t ncat = ipa_cat_n(d);
+    std::vector<float> wb_all, bb_all;
+    for (int l = 0; l < d.n_structure_layer; ++l) {
+        StructLayerW& S = h->st[l];
+        const float* hw = c.take(H);
+        const float* q_w = c.take(H * C * cs);            const float* q_b = c.take(H * C);
+        const float* kv_w = c.take(2 * H * C * cs);       const float* kv_b = c.take(2 * H * C);
+        const float* qp_w = c.take(3 * H * Pq * cs);      const float* qp_b = c.take(3 * H * Pq);
+        const float* kp_w = c.take(3 * H * (Pq + Pv) * cs); const float* kp_b = c.take(3 * H * (Pq + Pv));
+        const float* b_w = c.take(H * cp);                const float* b_b = c.take(H);
+        const float* o_w = c.take(cs * ncat);             const float* o_b = c.take(cs);
+        const float* li_g = c.take(cs); const float* li_b = c.take(cs);
+        const float* t1w = c.take(cs * cs); const float* t1b = c.take(cs);
+        const float* t2w = c.take(cs * cs); const float* t2b = c.take(cs);
+        const float* t3w = c.take(cs * cs); const float* t3b = c.take(cs);
+        const float* lt_g = c.take(cs); const float* lt_b = c.take(cs);
+        const float* bw = c.take(6 * cs); const float* bbs = c.take(6);
+        if (!bbs) { SET_ERR(h, "genie_load_weights: blob too short"); return GENIE_E_ARG; }
+        slot(&S.head_w, img.raw(hw, H));
+        auto w = vcat({{q_w, H * C * cs}, {kv_w, 2 * H * C * cs}, {qp_w, 3 * H * Pq * cs}, {kp_w, 3 * H * (Pq + Pv) * cs}});
+        auto bv = vcat({{q_b, H * C}, {kv_b, 2 * H * C}, {qp_b, 3 * H * Pq}, {kp_b, 3 * H * (Pq + Pv)}});
+        slot(&S.proj_w, img.pack(w.data(), ipa_proj_n(d), (int)cs));
+        slot(&S.proj_b, img.raw(bv.data(), bv.size()));
+        wb_all.insert(wb_all.end(), b_w, b_w + H * cp);
+        bb_all.insert(bb_all.end(), b_b, b_b + H);
+        slot(&S.out_w, img.pack(o_w, (int)cs, (int)ncat)); slot(&S.out_b, img.raw(o_b, cs));
+        slot(&S.ln_ipa_g, img.raw(li_g, cs)); slot(&S.ln_ipa_b, img.raw(li_b, cs));
+        slot(&S.t1_w, img.pack(t1w, (int)cs, (int)cs)); slot(&S.t1_b, img.raw(t1b, cs));
+        slot(&S.t2_w, img.pack(t2w, (int)cs, (int)cs)); slot(&S.t2_b, img.raw(t2b, cs));
+        slot(&S.t3_w, img.pack(t3w, (int)cs, (int)cs)); slot(&S.t3_b, img.raw(t3b, cs));
+        slot(&S.ln_tr_g, img.raw(lt_g, cs)); slot(&S.ln_tr_b, img.raw(lt_b, cs));
+        slot(&S.bb_w, img.raw(bw, 6 * cs)); slot(&S.bb_b, img.raw(bbs, 6));
+    }
+    slot(&h->ipa_bias_w, img.pack(wb_all.data(), (int)(d.n_structure_layer * H), (int)cp));
+    slot(&h->ipa_bias_b, img.raw(bb_all.data(), bb_all.size()));
+    if (c.left != 0) { SET_ERR(h, "genie_load_weights: %zu floats left over", c.left); return GENIE_E_ARG; }
+
+    if (h->wdev) { hipFree(h->wdev); h->wdev = nullptr; }
+    img.add(64);
+    HIP_TRY(h, hipMalloc((void**)&h->wdev, img.data.size() * sizeof(float)));
+    HIP_TRY(h, hipMemcpy(h->wdev, img.data.data(), img.data.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->wdev_floats = img.data.size();
+    for (auto& f : fix) *f.first = h->wdev + f.second;
+    h->have_weights = true;
+    return GENIE_OK;
+}
+
+// ------------------------------------------------------------------ tables
+int genie_set_tables(genie_handle_t h, const float* pos_tab, int n_pos, const float* chain_tab, int n_chain,
+                     const float* t_tab, const float* sched) {
+    if (!h || !pos_tab || !chain_tab || !t_tab || !sched || n_pos < 1 || n_chain < 1) return GENIE_E_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const genie_dims_t& d = h->d;
+    const size_t T1 = d.n_timestep + 1;
+    const size_t a = (size_t)n_pos * d.c_pos_emb, b = (size_t)n_chain * d.c_chain_emb, c = T1 * d.c_timestep_emb, s = 4 * T1;
+    if (h->pos_tab) hipFree(h->pos_tab);
+    HIP_TRY(h, hipMalloc((void**)&h->pos_tab, (a + b + c + s) * sizeof(float)));
+    h->chain_tab = h->pos_tab + a;
+    h->t_tab = h->chain_tab + b;
+    h->sched = h->t_tab + c;
+    HIP_TRY(h, hipMemcpy(h->pos_tab, pos_tab, a * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->chain_tab, chain_tab, b * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->t_tab, t_tab, c * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->sched, sched, s * sizeof(float), hipMemcpyHostToDevice));
+    free(h->sched_host);
+    h->sched_host = (float*)malloc(s * sizeof(float));
+    memcpy(h->sched_host, sched, s * sizeof(float));
+    h->n_pos = n_pos;
+    h->n_chain = n_chain;
+    h->have_tables = true;
+    return GENIE_OK;
+}
+
+// ------------------------------------------------------------------ batch binding
+__global__ void k_mask_to_float(const int32_t* m, float* f, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) f[i] = (float)m[i];
+}
+
+int genie_prepare_features(genie_handle_t h, genie_stream_t stream, int B, int N, const genie_features_t* f) {
+    if (!h || !f || B < 1 || N < 2) return GENIE_E_ARG;
+    if (!h->have_weights) { SET_ERR(h, "genie_prepare_features: weights not loaded"); return GENIE_E_STATE; }
+    const genie_dims_t& d = h->d;
+    if (ipa_attn_lds(d, N) > 160 * 1024) { SET_ERR(h, "N = %d exceeds the attention kernel's LDS budget", N); return GENIE_E_ARG; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int NP = (N + 31) / 32 * 32;
+    const size_t M = (size_t)B * N, P = M * N;
+    const size_t cs = d.c_s, cp = d.c_p;
+    const int H = d.n_head_ipa, C = d.c_hidden_ipa, Pq = d.n_qk_point, Pv = d.n_v_point;
+    const int ldx = (single_in(d) + 7) / 8 * 8;
+
+    // carve plan (bytes, 256-B aligned)
+    struct Seg { void** p; size_t bytes; };
+    std::vector<Seg> segs;
+    auto want = [&](void* pp, size_t bytes) { segs.push_back({(void**)pp, (bytes + 255) & ~(size_t)255}); };
+    want(&h->p, P * cp * 4); want(&h->pstatic, P * cp * 4);
+    want(&h->acm, (size_t)B * cp * NP * NP * 4); want(&h->bcm, (size_t)B * cp * NP * NP * 4); want(&h->xcm, (size_t)B * cp * NP * NP * 4);
+    want(&h->ipa_bias, (size_t)d.n_structure_layer * H * P * 4);
+    want(&h->xsingle, M * ldx * 4);
+    want(&h->s0, M * cs * 4); want(&h->s, M * cs * 4); want(&h->s1, M * cs * 4); want(&h->s2, M * cs * 4);
+    want(&h->h1, M * cs * 4); want(&h->h2, M * cs * 4);
+    want(&h->pij, M * 2 * cp * 4); want(&h->proj, M * ipa_proj_n(d) * 4); want(&h->cat, M * ipa_cat_n(d) * 4);
+    want(&h->kT, M * H * C * 4); want(&h->v, M * H * C * 4); want(&h->qp, M * H * Pq * 3 * 4);
+    want(&h->kpT, M * H * Pq * 3 * 4); want(&h->vp, M * H * Pv * 3 * 4);
+    want(&h->rots_w, M * 9 * 4); want(&h->trans_w, M * 3 * 4); want(&h->loop_z, M * 3 * 4);
+    want(&h->tsteps, (size_t)B * 4); want(&h->rmaskf, M * 4);
+    want(&h->f_aatype, M * 20 * 4); want(&h->f_rmask, M * 4); want(&h->f_ridx, M * 4); want(&h->f_cidx, M * 4);
+    want(&h->f_pos, M * 3 * 4); want(&h->f_fsm, M); want(&h->f_fstm, P); want(&h->f_ifm, M);
+    size_t total = 0;
+    for (auto& s : segs) total += s.bytes;
+    if (total > h->ws_bytes) {
+        free_batch(h);
+        hipError_t e = hipMalloc(&h->ws, total);
+        if (e != hipSuccess) { SET_ERR(h, "workspace hipMalloc(%zu MB) failed: %s", total >> 20, hipGetErrorString(e)); return GENIE_E_NOMEM; }
+        h->ws_bytes = total;
+    }
+    size_t off = 0;
+    for (auto& s : segs) { *s.p = (char*)h->ws + off; off += s.bytes; }
+    h->B = B; h->N = N; h->NP = NP;
+
+    HIP_TRY(h, hipMemcpyAsync(h->f_aatype, f->aatype, M * 20 * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->f_pos, f->atom_positions, M * 3 * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->f_rmask, f->residue_mask, M * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->f_ridx, f->residue_index, M * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->f_cidx, f->chain_index, M * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->f_fsm, f->fixed_sequence_mask, M, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->f_fstm, f->fixed_structure_mask, P, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->f_ifm, f->interface_mask, M, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_mask_to_float, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, h->f_rmask, h->rmaskf, (int)M);
+    // channel-major TriMul operands rely on zero padding beyond N
+    HIP_TRY(h, hipMemsetAsync(h->acm, 0, (size_t)B * cp * NP * NP * 4, st));
+    HIP_TRY(h, hipMemsetAsync(h->bcm, 0, (size_t)B * cp * NP * NP * 4, st));
+    single_kernels_init(d, N);
+    h->has_motif = true;   // the motif term is evaluated unconditionally (once per batch; zero when no motif is set)
+    launch_pair_static(h, st);
+    HIP_TRY(h, hipGetLastError());
+    h->have_feats = true;
+    return GENIE_OK;
+}
+
+// ------------------------------------------------------------------ denoiser
+static int denoise_internal(genie_ctx* h, hipStream_t st, const float* trans, const float* rots, const int32_t* ts_dev,
+                            const int8_t* codes, float* z_out, const genie_taps_t* taps) {
+    const genie_dims_t& d = h->d;
+    const int B = h->B, N = h->N, M = B * N;
+    const size_t P = (size_t)M * N;
+    const int cs = d.c_s, cp = d.c_p;
+    const int ldx = (single_in(d) + 7) / 8 * 8;
+    auto d2d = [&](void* dst, const void* src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st); };
+
+    launch_scale_copy(h, st, trans, h->trans_w, M * 3, d.rescale);
+    HIP_TRY(h, d2d(h->rots_w, rots, (size_t)M * 9 * 4));
+
+    // single feature net
+    launch_single_input(h, st, ts_dev);
+    launch_gemm_rows(h, st, h->xsingle, ldx, M, ldx, h->single_w, cs, nullptr, nullptr, 0, h->rmaskf, 0, h->s0, cs);
+    if (taps && taps->s) HIP_TRY(h, d2d(taps->s, h->s0, (size_t)M * cs * 4));
+
+    // pair feature net
+    launch_gemm_rows(h, st, h->s0, cs, M, cs, h->pij_w, 2 * cp, nullptr, nullptr, 0, nullptr, 0, h->pij, 2 * cp);
+    launch_pair_init(h, st, h->trans_w, h->rots_w, codes);
+    if (taps && taps->p_init) HIP_TRY(h, d2d(taps->p_init, h->p, P * cp * 4));
+
+    // pair transform net
+    for (int l = 0; l < d.n_pair_transform_layer; ++l) {
+        launch_trimul(h, st, h->pair[l].out, true);
+        launch_trimul(h, st, h->pair[l].in, false);
+        launch_pair_transition(h, st, h->pair[l]);
+        if (l == 0 && taps && taps->p_layer0) HIP_TRY(h, d2d(taps->p_layer0, h->p, P * cp * 4));
+    }
+    if (taps && taps->p) HIP_TRY(h, d2d(taps->p, h->p, P * cp * 4));
+
+    // structure net
+    launch_ipa_bias(h, st);
+    HIP_TRY(h, d2d(h->s, h->s0, (size_t)M * cs * 4));
+    const int nproj = ipa_proj_n(d), ncat = ipa_cat_n(d);
+    for (int blk = 0; blk < d.n_structure_block; ++blk) {
+        for (int l = 0; l < d.n_structure_layer; ++l) {
+            const StructLayerW& S = h->st[l];
+            const bool last = (blk == d.n_structure_block - 1) && (l == d.n_structure_layer - 1);
+            launch_gemm_rows(h, st, h->s, cs, M, cs, S.proj_w, nproj, S.proj_b, nullptr, 0, nullptr, 0, h->proj, nproj);
+            launch_ipa_prep(h, st);
+            launch_ipa_attn(h, st, l, S.head_w);
+            launch_gemm_rows(h, st, h->cat, ncat, M, ncat, S.out_w, cs, S.out_b, h->s, cs, nullptr, 0, h->s1, cs);
+            launch_layernorm_rows(h, st, h->s1, h->s2, M, cs, S.ln_ipa_g, S.ln_ipa_b);
+            launch_gemm_rows(h, st, h->s2, cs, M, cs, S.t1_w, cs, S.t1_b, nullptr, 0, nullptr, 1, h->h1, cs);
+            launch_gemm_rows(h, st, h->h1, cs, M, cs, S.t2_w, cs, S.t2_b, nullptr, 0, nullptr, 1, h->h2, cs);
+            launch_gemm_rows(h, st, h->h2, cs, M, cs, S.t3_w, cs, S.t3_b, h->s2, cs, nullptr, 0, h->s1, cs);
+            launch_layernorm_rows(h, st, h->s1, h->s, M, cs, S.ln_tr_g, S.ln_tr_b);
+            launch_bb_update(h, st, S, last ? trans : nullptr, last ? z_out : nullptr);
+        }
+    }
+    if (taps && taps->s_final) HIP_TRY(h, d2d(taps->s_final, h->s, (size_t)M * cs * 4));
+    if (taps && taps->rots_out) HIP_TRY(h, d2d(taps->rots_out, h->rots_w, (size_t)M * 9 * 4));
+    if (taps && taps->trans_out) launch_scale_copy(h, st, h->trans_w, taps->trans_out, M * 3, 1.0f / d.rescale);
+    HIP_TRY(h, hipGetLastError());
+    return GENIE_OK;
+}
+
+static int check_ready(genie_ctx* h, const char* who) {
+    if (!h) return GENIE_E_ARG;
+    if (!h->have_weights || !h->have_tables || !h->have_feats) {
+        SET_ERR(h, "%s: call genie_load_weights, genie_set_tables and genie_prepare_features first", who);
+        return GENIE_E_STATE;
+    }
+    if (hipSetDevice(h->device) != hipSuccess) { SET_ERR(h, "hipSetDevice failed"); return GENIE_E_HIP; }
+    return GENIE_OK;
+}
+
+int genie_denoise(genie_handle_t h, genie_stream_t stream, const float* trans, const float* rots, const int32_t* timesteps,
+                  const int8_t* quat_codes, float* z_out, const genie_taps_t* taps) {
+    if (int rc = check_ready(h, "genie_denoise")) return rc;
+    if (!trans || !rots || !timesteps || !z_out) { SET_ERR(h, "genie_denoise: null tensor"); return GENIE_E_ARG; }
+    return denoise_internal(h, (hipStream_t)stream, trans, rots, timesteps, quat_codes, z_out, taps);
+}
+
+int genie_frenet(genie_handle_t h, genie_stream_t stream, const float* trans, float* rots_out) {
+    if (!h || !h->have_feats) { if (h) SET_ERR(h, "genie_frenet: no batch bound"); return h ? GENIE_E_STATE : GENIE_E_ARG; }
+    if (!trans || !rots_out) return GENIE_E_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    launch_frenet(h, (hipStream_t)stream, 0, 0, 0.f, const_cast<float*>(trans), rots_out, nullptr, nullptr);
+    HIP_TRY(h, hipGetLastError());
+    return GENIE_OK;
+}
+
+int genie_p_sample(genie_handle_t h, genie_stream_t stream, int step, float scale, float* trans_inout, float* rots_out,
+                   const float* z, const float* eps) {
+    if (int rc = check_ready(h, "genie_p_sample")) return rc;
+    if (step < 1 || step > h->d.n_timestep || !trans_inout || !rots_out || !z) { SET_ERR(h, "genie_p_sample: bad argument"); return GENIE_E_ARG; }
+    launch_frenet(h, (hipStream_t)stream, 1, step, scale, trans_inout, rots_out, z, eps);
+    HIP_TRY(h, hipGetLastError());
+    return GENIE_OK;
+}
+
+int genie_sample_loop(genie_handle_t h, genie_stream_t stream, float scale, const float* noise, const int8_t* quat_codes,
+                      int first_step, int last_step, float* trans_io, float* rots_io, float* record) {
+    if (int rc = check_ready(h, "genie_sample_loop")) return rc;
+    const int T = h->d.n_timestep;
+    if (!noise || !trans_io || !rots_io || first_step > T || last_step < 1 || first_step < last_step) {
+        SET_ERR(h, "genie_sample_loop: bad argument");
+        return GENIE_E_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n3 = (size_t)h->B * h->N * 3, nn = (size_t)h->B * h->N * h->N;
+    if (first_step == T) {
+        HIP_TRY(h, hipMemcpyAsync(trans_io, noise, n3 * 4, hipMemcpyDeviceToDevice, st));
+        launch_frenet(h, st, 0, 0, 0.f, trans_io, rots_io, nullptr, nullptr);
+    }
+    int it = 0;
+    for (int step = first_step; step >= last_step; --step, ++it) {
+        launch_fill_i32(h, st, h->tsteps, h->B, step);
+        const int8_t* codes = quat_codes ? quat_codes + (size_t)it * nn : nullptr;
+        if (int rc = denoise_internal(h, st, trans_io, rots_io, h->tsteps, codes, h->loop_z, nullptr)) return rc;
+        const float* eps = (step == 1) ? nullptr : noise + (size_t)(T - step + 1) * n3;
+        launch_frenet(h, st, 1, step, scale, trans_io, rots_io, h->loop_z, eps);
+        if (record) HIP_TRY(h, hipMemcpyAsync(record + (size_t)it * n3, trans_io, n3 * 4, hipMemcpyDeviceToDevice, st));
+    }
+    HIP_TRY(h, hipGetLastError());
+    return GENIE_OK;
+}
+
+// ------------------------------------------------------------------ measurement
+int genie_profile_enable(genie_handle_t h, int enable) {
+    if (!h) return GENIE_E_ARG;
+    h->prof = enable != 0;
+    return GENIE_OK;
+}
+
+int genie_profile_read(genie_handle_t h, const char** names, double* total_ms, int64_t* launches, int cap) {
+    if (!h) return GENIE_E_ARG;
+    hipSetDevice(h->device);
+    for (int i = 0; i < h->prof_n; ++i) {
+        genie_ctx::ProfRec& r = h->prof_recs[i];
+        hipEventSynchronize(r.b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { h->prof_ms[r.cls] += ms; h->prof_cnt[r.cls] += 1; }
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    h->prof_n = 0;
+    int n = 0;
+    for (int k = 0; k < KC_COUNT && n < cap; ++k) {
+        if (names) names[n] = kKernelNames[k];
+        if (total_ms) total_ms[n] = h->prof_ms[k];
+        if (launches) launches[n] = h->prof_cnt[k];
+        ++n;
+    }
+    for (int k = 0; k < KC_COUNT; ++k) { h->prof_ms[k] = 0; h->prof_cnt[k] = 0; }
+    return n;
+}

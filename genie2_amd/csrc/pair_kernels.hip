@@ -1,0 +1,661 @@
+// Pair-track kernels: pair feature net, triangle multiplication, pair transition,
+// IPA pair bias.  All GEMMs are exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); see
+// common.h for the fragment convention.  Reference lines are cited per kernel.
+#include "common.h"
+
+#define LDZ 132   // 128-channel tile row stride (floats): conflict-free ds_read_b128
+#define LDX 68    // 64-wide M-contiguous tile row stride
+
+// Load 64 pair rows x 128 channels (row t at src + t*row_stride) into tile[64][LDZ].
+__device__ __forceinline__ void load_tile64(float* tile, const float* __restrict__ src, size_t row_stride,
+                                            int nvalid, int tid) {
+    const int c4 = tid & 31;
+    int r = tid >> 5;
+#pragma unroll
+    for (int u = 0; u < 8; ++u, r += 8) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < nvalid) v = *reinterpret_cast<const float4*>(src + (size_t)r * row_stride + c4 * 4);
+        *reinterpret_cast<float4*>(tile + r * LDZ + c4 * 4) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Triangle multiplication, projections
+// (modules/triangular_multiplicative_update.py:99-103):
+//   zn = LN_in(z); a = (W_ap zn + b)*sigmoid(W_ag zn + b)*mask; b likewise.
+// Output is channel-major a_cm[b][c][line][pos] (pos contiguous) so that the
+// contraction is one "NT" batched GEMM for both directions:
+//   outgoing: tile = row i of z,   line = i, pos = k = j    (a[i,k,c])
+//   incoming: tile = column j of z, line = j, pos = k = i   (a[k,i,c] stored as aT[i][k])
+// MFMA orientation: D rows = channels (A operand = W), D cols = pairs (lanes),
+// which makes every store a 128-B run.
+// ---------------------------------------------------------------------------
+template <bool OUTGOING>
+__global__ __launch_bounds__(256) void k_trimul_proj(const float* __restrict__ z, const float* __restrict__ rmask,
+                                                     const float* __restrict__ wp, const float* __restrict__ bias,
+                                                     const float* __restrict__ lng, const float* __restrict__ lnb,
+                                                     float* __restrict__ acm, float* __restrict__ bcm, int N, int NP) {
+    __shared__ __attribute__((aligned(16))) float zt[64 * LDZ];
+    __shared__ float msk[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntile = (N + 63) >> 6;
+    const int st = blockIdx.x % ntile;
+    const int line = (blockIdx.x / ntile) % N;
+    const int b = blockIdx.x / (ntile * N);
+    const int t0 = st * 64;
+    const int nvalid = min(64, N - t0);
+    const float* src;
+    size_t stride;
+    if (OUTGOING) { src = z + (((size_t)b * N + line) * N + t0) * 128; stride = 128; }
+    else          { src = z + (((size_t)b * N + t0) * N + line) * 128; stride = (size_t)N * 128; }
+    load_tile64(zt, src, stride, nvalid, tid);
+    if (tid < 64) msk[tid] = (tid < nvalid) ? rmask[b * N + line] * rmask[b * N + t0 + tid] : 0.f;
+    __syncthreads();
+    ln_rows_128(zt, LDZ, lng, lnb, tid);
+    __syncthreads();
+
+    for (int it = 0; it < 2; ++it) {
+        const int cg = wave + 4 * it;          // 0..3 -> a channels, 4..7 -> b channels
+        const int nb_p = cg, nb_g = 8 + cg;
+        f32x16 ap0 = zero16(), ap1 = zero16(), ag0 = zero16(), ag1 = zero16();
+#pragma unroll 4
+        for (int kb = 0; kb < 16; ++kb) {
+            const float4 wpf = wfrag(wp, 16, nb_p, kb, lane);
+            const float4 wgf = wfrag(wp, 16, nb_g, kb, lane);
+            const float4 z0 = lfrag(zt, LDZ, 0, kb, lane);
+            const float4 z1 = lfrag(zt, LDZ, 32, kb, lane);
+            ap0 = mfma_8k(wpf, z0, ap0);
+            ap1 = mfma_8k(wpf, z1, ap1);
+            ag0 = mfma_8k(wgf, z0, ag0);
+            ag1 = mfma_8k(wgf, z1, ag1);
+        }
+        float* dst = (cg < 4) ? acm : bcm;
+        const int chbase = (cg & 3) * 32;
+        const int t_lo = lane & 31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, lane);
+            const float bp = bias[nb_p * 32 + row], bg = bias[nb_g * 32 + row];
+            float* drow = dst + (((size_t)b * 128 + chbase + row) * NP + line) * NP + t0;
+            if (t_lo < nvalid) drow[t_lo] = (ap0[r] + bp) * sigmoidf_(ag0[r] + bg) * msk[t_lo];
+            if (t_lo + 32 < nvalid) drow[t_lo + 32] = (ap1[r] + bp) * sigmoidf_(ag1[r] + bg) * msk[t_lo + 32];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Triangle multiplication, contraction (trimul :57-82):
+//   x_cm[bc][i][j] = sum_k a_cm[bc][i][k] * b_cm[bc][j][k]   for bc = b*C + c.
+// WG tile (64*WT)^2, 4 waves of (32*WT)^2, K streamed in 32-wide chunks through
+// double-buffered LDS with register prefetch (one barrier per chunk).
+// ---------------------------------------------------------------------------
+#define LDK 36
+template <int WT>
+__global__ __launch_bounds__(256) void k_trimul_contract(const float* __restrict__ acm, const float* __restrict__ bcm,
+                                                         float* __restrict__ xcm, int NP) {
+    constexpr int TM = 64 * WT;
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [2 buf][A|B][TM*LDK]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles = (NP + TM - 1) / TM;
+    const int i0 = (blockIdx.x / tiles) * TM, j0 = (blockIdx.x % tiles) * TM;
+    const size_t mat = (size_t)blockIdx.y * NP * NP;
+    const float* A = acm + mat;
+    const float* Bm = bcm + mat;
+    const int lr = tid >> 3, c4 = tid & 7;
+    float4 ra[TM / 32], rb[TM / 32];
+    const int nk = NP / 32;
+
+    auto gload = [&](int kc) {
+#pragma unroll
+        for (int u = 0; u < TM / 32; ++u) {
+            const int r = lr + 32 * u;
+            ra[u] = (i0 + r < NP) ? *reinterpret_cast<const float4*>(A + (size_t)(i0 + r) * NP + kc * 32 + c4 * 4)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[u] = (j0 + r < NP) ? *reinterpret_cast<const float4*>(Bm + (size_t)(j0 + r) * NP + kc * 32 + c4 * 4)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto swrite = [&](int buf) {
+        float* sa = sm + buf * 2 * TM * LDK;
+        float* sb = sa + TM * LDK;
+#pragma unroll
+        for (int u = 0; u < TM / 32; ++u) {
+            const int r = lr + 32 * u;
+            *reinterpret_cast<float4*>(sa + r * LDK + c4 * 4) = ra[u];
+            *reinterpret_cast<float4*>(sb + r * LDK + c4 * 4) = rb[u];
+        }
+    };
+
+    f32x16 acc[WT][WT];
+#pragma unroll
+    for (int m = 0; m < WT; ++m)
+#pragma unroll
+        for (int n = 0; n < WT; ++n) acc[m][n] = zero16();
+
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+        if (kc + 1 < nk) gload(kc + 1);
+        const float* sa = sm + (kc & 1) * 2 * TM * LDK;
+        const float* sb = sa + TM * LDK;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            float4 af[WT], bf[WT];
+#pragma unroll
+            for (int m = 0; m < WT; ++m) af[m] = lfrag(sa, LDK, (wm * WT + m) * 32, kb, lane);
+#pragma unroll
+            for (int n = 0; n < WT; ++n) bf[n] = lfrag(sb, LDK, (wn * WT + n) * 32, kb, lane);
+#pragma unroll
+            for (int m = 0; m < WT; ++m)
+#pragma unroll
+                for (int n = 0; n < WT; ++n) acc[m][n] = mfma_8k(af[m], bf[n], acc[m][n]);
+        }
+        if (kc + 1 < nk) swrite((kc + 1) & 1);
+        __syncthreads();
+    }
+    float* X = xcm + mat;
+#pragma unroll
+    for (int m = 0; m < WT; ++m)
+#pragma unroll
+        for (int n = 0; n < WT; ++n) {
+            const int j = j0 + (wn * WT + n) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + (wm * WT + m) * 32 + acc_row(r, lane);
+                if (i < NP && j < NP) X[(size_t)i * NP + j] = acc[m][n][r];
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------
+// Triangle multiplication, output (trimul :105-108 + residual
+// pair_transform_net.py:111-112):
+//   z += (W_z LN_out(x) + b_z) * sigmoid(W_g LN_in(z) + b_g)
+// The gate is computed here from the z tile the residual needs anyway, so g
+// never goes through HBM.  x arrives channel-major and is consumed as an
+// M-contiguous LDS tile [c][j].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_trimul_out(float* __restrict__ z, const float* __restrict__ xcm,
+                                                    const float* __restrict__ wg, const float* __restrict__ bg,
+                                                    const float* __restrict__ wz, const float* __restrict__ bz,
+                                                    const float* __restrict__ ln_in_g, const float* __restrict__ ln_in_b,
+                                                    const float* __restrict__ ln_out_g, const float* __restrict__ ln_out_b,
+                                                    int N, int NP) {
+    __shared__ __attribute__((aligned(16))) float buf[128 * LDX];   // >= 64*LDZ
+    __shared__ float red[4][64];
+    __shared__ float st_mean[64], st_rstd[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntile = (N + 63) >> 6;
+    const int st = blockIdx.x % ntile;
+    const int i = (blockIdx.x / ntile) % N;
+    const int b = blockIdx.x / (ntile * N);
+    const int t0 = st * 64;
+    const int nvalid = min(64, N - t0);
+    float* zrow = z + (((size_t)b * N + i) * N + t0) * 128;
+
+    load_tile64(buf, zrow, 128, nvalid, tid);
+    __syncthreads();
+    ln_rows_128(buf, LDZ, ln_in_g, ln_in_b, tid);
+    __syncthreads();
+    f32x16 g0 = zero16(), g1 = zero16();
+#pragma unroll 4
+    for (int kb = 0; kb < 16; ++kb) {
+        const float4 w = wfrag(wg, 16, wave, kb, lane);
+        g0 = mfma_8k(lfrag(buf, LDZ, 0, kb, lane), w, g0);
+        g1 = mfma_8k(lfrag(buf, LDZ, 32, kb, lane), w, g1);
+    }
+    const int ch = wave * 32 + (lane & 31);
+    {
+        const float bgc = bg[ch];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { g0[r] = sigmoidf_(g0[r] + bgc); g1[r] = sigmoidf_(g1[r] + bgc); }
+    }
+    __syncthreads();   // everyone is done reading the z tile
+
+    // x tile: xt[c][j], c = 0..127, j = t0..t0+63
+    {
+        const int f4 = tid & 15;
+        const int j = t0 + 4 * f4;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = (tid >> 4) + 16 * u;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < NP) v = *reinterpret_cast<const float4*>(xcm + (((size_t)b * 128 + c) * NP + i) * NP + j);
+            *reinterpret_cast<float4*>(buf + c * LDX + 4 * f4) = v;
+        }
+    }
+    __syncthreads();
+    // LN_out over c for each j (4 threads per j, 32 channels each)
+    {
+        const int j = tid & 63, part = tid >> 6;
+        float s = 0.f;
+#pragma unroll 8
+        for (int q = 0; q < 32; ++q) s += buf[(part * 32 + q) * LDX + j];
+        red[part][j] = s;
+        __syncthreads();
+        const float mean = (red[0][j] + red[1][j] + red[2][j] + red[3][j]) * (1.0f / 128.0f);
+        __syncthreads();
+        float ss = 0.f;
+#pragma unroll 8
+        for (int q = 0; q < 32; ++q) { const float d = buf[(part * 32 + q) * LDX + j] - mean; ss += d * d; }
+        red[part][j] = ss;
+        __syncthreads();
+        const float var = (red[0][j] + red[1][j] + red[2][j] + red[3][j]) * (1.0f / 128.0f);
+        const float rstd = 1.0f / sqrtf(var + GENIE_LN_EPS);
+#pragma unroll 8
+        for (int q = 0; q < 32; ++q) {
+            const int c = part * 32 + q;
+            buf[c * LDX + j] = (buf[c * LDX + j] - mean) * rstd * ln_out_g[c] + ln_out_b[c];
+        }
+    }
+    __syncthreads();
+    f32x16 a0 = zero16(), a1 = zero16();
+#pragma unroll 4
+    for (int kb = 0; kb < 16; ++kb) {
+        const float4 w = wfrag(wz, 16, wave, kb, lane);
+        a0 = mfma_8k(lfrag_t(buf, LDX, 0, kb, lane), w, a0);
+        a1 = mfma_8k(lfrag_t(buf, LDX, 32, kb, lane), w, a1);
+    }
+    const float bzc = bz[ch];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int t = acc_row(r, lane);
+        if (t < nvalid) { float* q = zrow + (size_t)t * 128 + ch; *q = (a0[r] + bzc) * g0[r] + *q; }
+        if (t + 32 < nvalid) { float* q = zrow + (size_t)(t + 32) * 128 + ch; *q = (a1[r] + bzc) * g1[r] + *q; }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Pair transition + end-of-layer mask (modules/pair_transition.py:48-56,
+// pair_transform_net.py:116-117):
+//   z = (z + mask * (W2 relu(W1 LN(z) + b1) + b2)) * mask
+// 64 rows per WG; the 512-wide hidden layer lives only in registers / LDS
+// (four 128-wide chunks).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pair_transition(float* __restrict__ z, const float* __restrict__ rmask,
+                                                         const float* __restrict__ lng, const float* __restrict__ lnb,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         const float* __restrict__ w2, const float* __restrict__ b2,
+                                                         int N, long long M, int n_chunk) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* zt = sm;
+    float* ht = sm + 64 * LDZ;
+    float* msk = ht + 64 * LDZ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long row0 = (long long)blockIdx.x * 64;
+    const int nvalid = (int)min((long long)64, M - row0);
+    float* zrow = z + row0 * 128;
+    load_tile64(zt, zrow, 128, nvalid, tid);
+    if (tid < 64) {
+        float m = 0.f;
+        if (tid < nvalid) {
+            const long long idx = row0 + tid;
+            const int b = (int)(idx / ((long long)N * N));
+            const int rem = (int)(idx - (long long)b * N * N);
+            m = rmask[b * N + rem / N] * rmask[b * N + rem % N];
+        }
+        msk[tid] = m;
+    }
+    __syncthreads();
+    ln_rows_128(zt, LDZ, lng, lnb, tid);
+    __syncthreads();
+    const int KB2 = n_chunk * 16;
+    f32x16 o0 = zero16(), o1 = zero16();
+    const int col = wave * 32 + (lane & 31);
+    for (int hc = 0; hc < n_chunk; ++hc) {
+        f32x16 h0 = zero16(), h1 = zero16();
+#pragma unroll 4
+        for (int kb = 0; kb < 16; ++kb) {
+            const float4 w = wfrag(w1, 16, hc * 4 + wave, kb, lane);
+            h0 = mfma_8k(lfrag(zt, LDZ, 0, kb, lane), w, h0);
+            h1 = mfma_8k(lfrag(zt, LDZ, 32, kb, lane), w, h1);
+        }
+        const float bb = b1[hc * 128 + col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = acc_row(r, lane);
+            ht[t * LDZ + col] = fmaxf(h0[r] + bb, 0.f);
+            ht[(t + 32) * LDZ + col] = fmaxf(h1[r] + bb, 0.f);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kb = 0; kb < 16; ++kb) {
+            const float4 w = wfrag(w2, KB2, wave, hc * 16 + kb, lane);
+            o0 = mfma_8k(lfrag(ht, LDZ, 0, kb, lane), w, o0);
+            o1 = mfma_8k(lfrag(ht, LDZ, 32, kb, lane), w, o1);
+        }
+        __syncthreads();
+    }
+    const float b2c = b2[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int t = acc_row(r, lane);
+        if (t < nvalid) { float* q = zrow + (size_t)t * 128 + col; const float m = msk[t]; *q = ((o0[r] + b2c) * m + *q) * m; }
+        if (t + 32 < nvalid) { float* q = zrow + (size_t)(t + 32) * 128 + col; const float m = msk[t + 32]; *q = ((o1[r] + b2c) * m + *q) * m; }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// IPA pair bias for ALL structure layers in one pass over p
+// (modules/invariant_point_attention.py:181): bias[l*H+h][b][i][j] = W_b^l z_ij + b.
+// 128 pairs per WG; D rows = (layer, head), D cols = pairs -> j-contiguous rows
+// for the attention kernel.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ipa_bias(const float* __restrict__ z, const float* __restrict__ wp,
+                                                  const float* __restrict__ bias, float* __restrict__ out,
+                                                  int B, int N, int LH) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [128][LDZ]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntile = (N + 127) >> 7;
+    const int st = blockIdx.x % ntile;
+    const int i = (blockIdx.x / ntile) % N;
+    const int b = blockIdx.x / (ntile * N);
+    const int t0 = st * 128;
+    const int nvalid = min(128, N - t0);
+    const float* src = z + (((size_t)b * N + i) * N + t0) * 128;
+    load_tile64(sm, src, 128, nvalid, tid);
+    load_tile64(sm + 64 * LDZ, src + (size_t)64 * 128, 128, nvalid - 64, tid);
+    __syncthreads();
+    const int nbo = (LH + 31) >> 5;
+    const int t = wave * 32 + (lane & 31);
+    for (int ob = 0; ob < nbo; ++ob) {
+        f32x16 acc = zero16();
+#pragma unroll 4
+        for (int kb = 0; kb < 16; ++kb)
+            acc = mfma_8k(wfrag(wp, 16, ob, kb, lane), lfrag(sm, LDZ, wave * 32, kb, lane), acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = ob * 32 + acc_row(r, lane);
+            if (o < LH && t < nvalid) out[(((size_t)o * B + b) * N + i) * N + t0 + t] = acc[r] + bias[o];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Pair feature net.  Shared feature builder: softmax(-4|d - v_k|) soft bins
+// (pair_feature_net.py:239-269, fork-specific) for 64 pairs (b, i, t0..t0+63):
+// 4 lanes per pair, bins interleaved, reductions by wave shuffles.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void soft_bins(float* frow, float d, float dmin, float dstep, int nbin, float pm, int part) {
+    float x[10];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+        const int k = part + 4 * q;
+        x[q] = (k < nbin) ? -4.0f * fabsf(d - (dmin + (float)k * dstep)) : -3.0e38f;
+        mx = fmaxf(mx, x[q]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 1));
+    mx = fmaxf(mx, __shfl_xor(mx, 2));
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+        const int k = part + 4 * q;
+        x[q] = (k < nbin) ? expf(x[q] - mx) : 0.f;
+        s += x[q];
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+        const int k = part + 4 * q;
+        if (k < nbin) frow[k] = (x[q] / s) * pm;
+    }
+}
+
+// Quaternion of a proper rotation r (row-major 3x3): normalised column of
+// K + I with the largest diagonal (closed form of the eigenvector that
+// affine_utils.py:336-355 obtains with eigh), sign pinned by `code`.
+__device__ __forceinline__ void rot_to_quat_dev(const float* r, int code, float* q) {
+    const float xx = r[0], xy = r[1], xz = r[2], yx = r[3], yy = r[4], yz = r[5], zx = r[6], zy = r[7], zz = r[8];
+    const float d0 = 1.f + xx + yy + zz, d1 = 1.f + xx - yy - zz, d2 = 1.f + yy - xx - zz, d3 = 1.f + zz - xx - yy;
+    float c0, c1, c2, c3;
+    if (d0 >= d1 && d0 >= d2 && d0 >= d3)      { c0 = d0;      c1 = zy - yz; c2 = xz - zx; c3 = yx - xy; }
+    else if (d1 >= d2 && d1 >= d3)             { c0 = zy - yz; c1 = d1;      c2 = xy + yx; c3 = xz + zx; }
+    else if (d2 >= d3)                         { c0 = xz - zx; c1 = xy + yx; c2 = d2;      c3 = yz + zy; }
+    else                                       { c0 = yx - xy; c1 = xz + zx; c2 = yz + zy; c3 = d3; }
+    const float inv = 1.0f / sqrtf(c0 * c0 + c1 * c1 + c2 * c2 + c3 * c3);
+    q[0] = c0 * inv; q[1] = c1 * inv; q[2] = c2 * inv; q[3] = c3 * inv;
+    if (code > 0) {
+        const int m = (code - 1) >> 1;
+        const bool want_neg = ((code - 1) & 1) != 0;
+        const float comp = q[m];
+        if ((comp < 0.f) != want_neg) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    }
+}
+
+// p = (p_i + p_j + static + W_t [bins | quat | fsm | fsm]) * mask
+// (pair_feature_net.py:117-160).  static = relpos + motif term (k_pair_static).
+#define LDF 52   // 48 features + 4 pad
+__global__ __launch_bounds__(256) void k_pair_init(const float* __restrict__ trans, const float* __restrict__ rots,
+                                                   const int8_t* __restrict__ codes, const float* __restrict__ rmask,
+                                                   const uint8_t* __restrict__ fstm, const float* __restrict__ pij,
+                                                   const float* __restrict__ pstatic, const float* __restrict__ wt,
+                                                   float* __restrict__ p, int N, float dmin, float dstep, int nbin) {
+    __shared__ __attribute__((aligned(16))) float ft[64 * LDF];
+    __shared__ float pmk[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntile = (N + 63) >> 6;
+    const int st = blockIdx.x % ntile;
+    const int i = (blockIdx.x / ntile) % N;
+    const int b = blockIdx.x / (ntile * N);
+    const int t0 = st * 64;
+    const int nvalid = min(64, N - t0);
+    {
+        const int jl = tid >> 2, part = tid & 3;
+        float* frow = ft + jl * LDF;
+        if (jl < nvalid) {
+            const int j = t0 + jl;
+            const float pm = rmask[b * N + i] * rmask[b * N + j];
+            const float* xi = trans + ((size_t)b * N + i) * 3;
+            const float* xj = trans + ((size_t)b * N + j) * 3;
+            const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
+            const float d = sqrtf(1e-10f + ((dx * dx + dy * dy) + dz * dz));
+            soft_bins(frow, d, dmin, dstep, nbin, pm, part);
+            if (part == 0) {
+                const float* Ri = rots + ((size_t)b * N + i) * 9;
+                const float* Rj = rots + ((size_t)b * N + j) * 9;
+                float r[9];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        r[a * 3 + c] = Rj[a * 3 + 0] * Ri[0 * 3 + c] + Rj[a * 3 + 1] * Ri[1 * 3 + c] + Rj[a * 3 + 2] * Ri[2 * 3 + c];
+                float q[4];
+                const size_t pidx = ((size_t)b * N + i) * N + j;
+                rot_to_quat_dev(r, codes ? (int)codes[pidx] : 0, q);
+                const float f = fstm[pidx] ? 1.f : 0.f;
+                frow[nbin + 0] = q[0] * pm; frow[nbin + 1] = q[1] * pm; frow[nbin + 2] = q[2] * pm; frow[nbin + 3] = q[3] * pm;
+                frow[nbin + 4] = f; frow[nbin + 5] = f;
+                for (int k = nbin + 6; k < 48; ++k) frow[k] = 0.f;
+                pmk[jl] = pm;
+            }
+        } else {
+            for (int k = part; k < 48; k += 4) frow[k] = 0.f;
+            if (part == 0) pmk[jl] = 0.f;
+        }
+    }
+    __syncthreads();
+    f32x16 a0 = zero16(), a1 = zero16();
+#pragma unroll
+    for (int kb = 0; kb < 6; ++kb) {
+        const float4 w = wfrag(wt, 6, wave, kb, lane);
+        a0 = mfma_8k(lfrag(ft, LDF, 0, kb, lane), w, a0);
+        a1 = mfma_8k(lfrag(ft, LDF, 32, kb, lane), w, a1);
+    }
+    const int ch = wave * 32 + (lane & 31);
+    const float pi_c = pij[((size_t)b * N + i) * 256 + ch];
+    const size_t prow0 = ((size_t)b * N + i) * N + t0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int t = acc_row(r, lane) + 32 * hf;
+            if (t < nvalid) {
+                const float acc = hf ? a1[r] : a0[r];
+                const float pj_c = pij[((size_t)b * N + t0 + t) * 256 + 128 + ch];
+                const size_t o = (prow0 + t) * 128 + ch;
+                p[o] = (acc + pi_c + pj_c + pstatic[o]) * pmk[t];
+            }
+        }
+    }
+}
+
+// Step-invariant pair terms (pair_feature_net.py:134,149-158,166-221):
+//   static = W_relpos[:, d_ij] + same_chain * W_relpos[:, 66]
+//          + W_motif [bins(atom_positions) * fsm_i fsm_j * fstm_ij | fstm | fstm]
+#define LDM 44   // 40 features + 4 pad
+template <bool MOTIF>
+__global__ __launch_bounds__(256) void k_pair_static(const float* __restrict__ pos, const int32_t* __restrict__ ridx,
+                                                     const int32_t* __restrict__ cidx, const uint8_t* __restrict__ fsm,
+                                                     const uint8_t* __restrict__ fstm, const float* __restrict__ relpos_t,
+                                                     const float* __restrict__ wm, float* __restrict__ pstatic, int N,
+                                                     int relpos_k, float dmin, float dstep, int nbin) {
+    __shared__ __attribute__((aligned(16))) float ft[64 * LDM];
+    __shared__ int dsel[64];
+    __shared__ float same[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntile = (N + 63) >> 6;
+    const int st = blockIdx.x % ntile;
+    const int i = (blockIdx.x / ntile) % N;
+    const int b = blockIdx.x / (ntile * N);
+    const int t0 = st * 64;
+    const int nvalid = min(64, N - t0);
+    {
+        const int jl = tid >> 2, part = tid & 3;
+        float* frow = ft + jl * LDM;
+        if (jl < nvalid) {
+            const int j = t0 + jl;
+            const size_t pidx = ((size_t)b * N + i) * N + j;
+            if (MOTIF) {
+                const float f = fstm[pidx] ? 1.f : 0.f;
+                const float pm = ((fsm[b * N + i] && fsm[b * N + j]) ? 1.f : 0.f) * f;
+                const float* xi = pos + ((size_t)b * N + i) * 3;
+                const float* xj = pos + ((size_t)b * N + j) * 3;
+                const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
+                const float d = sqrtf(1e-10f + ((dx * dx + dy * dy) + dz * dz));
+                soft_bins(frow, d, dmin, dstep, nbin, pm, part);
+                if (part == 0) { frow[nbin] = f; frow[nbin + 1] = f; for (int k = nbin + 2; k < 40; ++k) frow[k] = 0.f; }
+            }
+            if (part == 0) {
+                const bool sc = cidx[b * N + i] == cidx[b * N + j];
+                int dd = ridx[b * N + i] - ridx[b * N + j] + relpos_k;
+                dd = max(0, min(dd, 2 * relpos_k));
+                dsel[jl] = sc ? dd : 2 * relpos_k + 1;
+                same[jl] = sc ? 1.f : 0.f;
+            }
+        } else if (MOTIF) {
+            for (int k = part; k < 40; k += 4) frow[k] = 0.f;
+        }
+    }
+    __syncthreads();
+    f32x16 a0 = zero16(), a1 = zero16();
+    if (MOTIF) {
+#pragma unroll
+        for (int kb = 0; kb < 5; ++kb) {
+            const float4 w = wfrag(wm, 5, wave, kb, lane);
+            a0 = mfma_8k(lfrag(ft, LDM, 0, kb, lane), w, a0);
+            a1 = mfma_8k(lfrag(ft, LDM, 32, kb, lane), w, a1);
+        }
+    }
+    const int ch = wave * 32 + (lane & 31);
+    const float w_same = relpos_t[(2 * relpos_k + 2) * 128 + ch];
+    const size_t prow0 = ((size_t)b * N + i) * N + t0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int t = acc_row(r, lane) + 32 * hf;
+            if (t < nvalid) {
+                const float acc = hf ? a1[r] : a0[r];
+                pstatic[(prow0 + t) * 128 + ch] = (relpos_t[dsel[t] * 128 + ch] + same[t] * w_same) + acc;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+void launch_pair_static(genie_ctx* h, hipStream_t st) {
+    ProfScope ps(h, st, KC_PAIR_STATIC);
+    const int N = h->N, ntile = (N + 63) / 64;
+    dim3 grid(h->B * N * ntile);
+    if (h->has_motif)
+        hipLaunchKernelGGL(k_pair_static<true>, grid, dim3(256), 0, st, h->f_pos, h->f_ridx, h->f_cidx, h->f_fsm, h->f_fstm,
+                           h->relpos_t, h->motif_w, h->pstatic, N, h->d.relpos_k, h->d.template_dist_min,
+                           h->d.template_dist_step, h->d.template_dist_n_bin);
+    else
+        hipLaunchKernelGGL(k_pair_static<false>, grid, dim3(256), 0, st, h->f_pos, h->f_ridx, h->f_cidx, h->f_fsm, h->f_fstm,
+                           h->relpos_t, h->motif_w, h->pstatic, N, h->d.relpos_k, h->d.template_dist_min,
+                           h->d.template_dist_step, h->d.template_dist_n_bin);
+}
+
+void launch_pair_init(genie_ctx* h, hipStream_t st, const float* trans, const float* rots, const int8_t* codes) {
+    ProfScope ps(h, st, KC_PAIR_INIT);
+    const int N = h->N, ntile = (N + 63) / 64;
+    hipLaunchKernelGGL(k_pair_init, dim3(h->B * N * ntile), dim3(256), 0, st, trans, rots, codes, h->rmaskf, h->f_fstm,
+                       h->pij, h->pstatic, h->templ_w, h->p, N, h->d.template_dist_min, h->d.template_dist_step,
+                       h->d.template_dist_n_bin);
+}
+
+void launch_trimul(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgoing) {
+    const int N = h->N, NP = h->NP, ntile = (N + 63) / 64;
+    {
+        ProfScope ps(h, st, KC_TRIMUL_PROJ);
+        dim3 grid(h->B * N * ntile);
+        if (outgoing)
+            hipLaunchKernelGGL(k_trimul_proj<true>, grid, dim3(256), 0, st, h->p, h->rmaskf, w.proj_w, w.proj_b, w.ln_in_g,
+                               w.ln_in_b, h->acm, h->bcm, N, NP);
+        else
+            hipLaunchKernelGGL(k_trimul_proj<false>, grid, dim3(256), 0, st, h->p, h->rmaskf, w.proj_w, w.proj_b, w.ln_in_g,
+                               w.ln_in_b, h->acm, h->bcm, N, NP);
+    }
+    {
+        ProfScope ps(h, st, KC_TRIMUL_CONTRACT);
+        const int BC = h->B * h->d.c_hidden_mul;
+        if (NP >= 128) {
+            const int tiles = (NP + 127) / 128;
+            const size_t lds = 2 * 2 * 128 * LDK * sizeof(float);
+            hipLaunchKernelGGL(k_trimul_contract<2>, dim3(tiles * tiles, BC), dim3(256), lds, st, h->acm, h->bcm, h->xcm, NP);
+        } else {
+            const int tiles = (NP + 63) / 64;
+            const size_t lds = 2 * 2 * 64 * LDK * sizeof(float);
+            hipLaunchKernelGGL(k_trimul_contract<1>, dim3(tiles * tiles, BC), dim3(256), lds, st, h->acm, h->bcm, h->xcm, NP);
+        }
+    }
+    {
+        ProfScope ps(h, st, KC_TRIMUL_OUT);
+        hipLaunchKernelGGL(k_trimul_out, dim3(h->B * N * ntile), dim3(256), 0, st, h->p, h->xcm, w.g_w, w.g_b, w.z_w, w.z_b,
+                           w.ln_in_g, w.ln_in_b, w.ln_out_g, w.ln_out_b, N, NP);
+    }
+}
+
+void launch_pair_transition(genie_ctx* h, hipStream_t st, const PairLayerW& w) {
+    ProfScope ps(h, st, KC_PAIR_TRANSITION);
+    const long long M = (long long)h->B * h->N * h->N;
+    const size_t lds = (2 * 64 * LDZ + 64) * sizeof(float);
+    hipLaunchKernelGGL(k_pair_transition, dim3((unsigned)((M + 63) / 64)), dim3(256), lds, st, h->p, h->rmaskf, w.pt_ln_g,
+                       w.pt_ln_b, w.pt_w1, w.pt_b1, w.pt_w2, w.pt_b2, h->N, M, h->d.pair_transition_n);
+}
+
+void launch_ipa_bias(genie_ctx* h, hipStream_t st) {
+    ProfScope ps(h, st, KC_IPA_BIAS);
+    const int N = h->N, ntile = (N + 127) / 128;
+    const int LH = h->d.n_structure_layer * h->d.n_head_ipa;
+    const size_t lds = 128 * LDZ * sizeof(float);
+    hipLaunchKernelGGL(k_ipa_bias, dim3(h->B * N * ntile), dim3(256), lds, st, h->p, h->ipa_bias_w, h->ipa_bias_b, h->ipa_bias,
+                       h->B, N, LH);
+}
+
+// One-time opt-in to > 64 KiB dynamic LDS.
+void pair_kernels_init() {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_trimul_contract<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        2 * 2 * 128 * LDK * sizeof(float));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_transition), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (2 * 64 * LDZ + 64) * sizeof(float));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_bias), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        128 * LDZ * sizeof(float));
+}

@@ -1,0 +1,559 @@
+// Single-track kernels: single feature net, row GEMMs, LayerNorm, invariant
+// point attention, backbone update.  Reference lines are cited per kernel.
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+// Single feature net input (single_feature_net.py:103-142): one row per
+// residue, [pos | chain | t | aatype*fsm | fsm | fsm | interface | 0-pad].
+// The sinusoidal tables come from the host (encoding.py:5-25 evaluated with
+// the reference's own torch expression), so no sin/cos/pow runs on device.
+// ---------------------------------------------------------------------------
+__global__ void k_single_input(float* __restrict__ x, int ldx, const float* __restrict__ pos_tab, int n_pos, int c_pos,
+                               const float* __restrict__ chain_tab, int n_chain, int c_chain,
+                               const float* __restrict__ t_tab, int c_t, const int32_t* __restrict__ timesteps,
+                               const int32_t* __restrict__ ridx, const int32_t* __restrict__ cidx,
+                               const int32_t* __restrict__ aatype, const uint8_t* __restrict__ fsm,
+                               const uint8_t* __restrict__ ifm, int N, int n_timestep) {
+    const int row = blockIdx.x;           // b*N + n
+    const int b = row / N;
+    float* xr = x + (size_t)row * ldx;
+    const int ri = min(max(ridx[row], 0), n_pos - 1);
+    const int ci = min(max(cidx[row], 0), n_chain - 1);
+    const int ts = min(max(timesteps[b], 0), n_timestep);
+    const float f = fsm[row] ? 1.f : 0.f;
+    const int o1 = c_pos, o2 = o1 + c_chain, o3 = o2 + c_t, o4 = o3 + 20;
+    for (int c = threadIdx.x; c < ldx; c += blockDim.x) {
+        float v;
+        if (c < o1) v = pos_tab[(size_t)ri * c_pos + c];
+        else if (c < o2) v = chain_tab[(size_t)ci * c_chain + (c - o1)];
+        else if (c < o3) v = t_tab[(size_t)ts * c_t + (c - o2)];
+        else if (c < o4) v = (float)aatype[(size_t)row * 20 + (c - o3)] * f;
+        else if (c < o4 + 2) v = f;
+        else if (c == o4 + 2) v = ifm[row] ? 1.f : 0.f;
+        else v = 0.f;
+        xr[c] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// out[M][Nout] = epi(A[M][K] W^T):  epi = (+bias) (relu) (+res) (*rowmask).
+// 32 rows x 128 cols per WG (4 waves, one 32x32 MFMA tile each); A streamed in
+// 64-wide K chunks through double-buffered LDS, W fragments straight from L2.
+// Serves primitives.Linear (primitives.py:96-160) wherever the row count is
+// B*N: single feature net, p_i/p_j, IPA projections and output, transition.
+// ---------------------------------------------------------------------------
+#define LDA 68
+__global__ __launch_bounds__(256) void k_gemm_rows(const float* __restrict__ A, int lda, int M, int K,
+                                                   const float* __restrict__ Wp, int Nout,
+                                                   const float* __restrict__ bias, const float* __restrict__ res, int ldr,
+                                                   const float* __restrict__ rowmask, int relu, float* __restrict__ out, int ldo) {
+    __shared__ __attribute__((aligned(16))) float sa[2][32 * LDA];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * 32;
+    const int nb = blockIdx.y * 4 + wave;
+    const int KB = (K + 7) >> 3;
+    const int nkc = (K + 63) >> 6;
+    const bool active = nb * 32 < Nout;
+    const int lr = tid >> 4, c4 = tid & 15;      // 16 rows x 16 float4 per pass, 2 passes
+    float4 ra[2];
+    auto gload = [&](int kc) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = r0 + lr + 16 * u, k = kc * 64 + c4 * 4;
+            ra[u] = (r < M && k < K) ? *reinterpret_cast<const float4*>(A + (size_t)r * lda + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) *reinterpret_cast<float4*>(&sa[buf][(lr + 16 * u) * LDA + c4 * 4]) = ra[u];
+    };
+    f32x16 acc = zero16();
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int kc = 0; kc < nkc; ++kc) {
+        if (kc + 1 < nkc) gload(kc + 1);
+        if (active) {
+            const int kbn = min(8, KB - kc * 8);
+#pragma unroll 4
+            for (int kb = 0; kb < kbn; ++kb)
+                acc = mfma_8k(lfrag(sa[kc & 1], LDA, 0, kb, lane), wfrag(Wp, KB, nb, kc * 8 + kb, lane), acc);
+        }
+        if (kc + 1 < nkc) swrite((kc + 1) & 1);
+        __syncthreads();
+    }
+    if (!active) return;
+    const int col = nb * 32 + (lane & 31);
+    if (col >= Nout) return;
+    const float bc = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = r0 + acc_row(r, lane);
+        if (row < M) {
+            float v = acc[r] + bc;
+            if (relu) v = fmaxf(v, 0.f);
+            if (res) v += res[(size_t)row * ldr + col];
+            if (rowmask) v *= rowmask[row];
+            out[(size_t)row * ldo + col] = v;
+        }
+    }
+}
+
+// nn.LayerNorm over the last dim, one wave per row (structure_net.py:64,111;
+// structure_transition.py:61).  C <= 64*8.
+__global__ __launch_bounds__(256) void k_layernorm_rows(const float* __restrict__ in, float* __restrict__ out, int M, int C,
+                                                        const float* __restrict__ g, const float* __restrict__ bta) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* x = in + (size_t)row * C;
+    float v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int c = lane + 64 * q; v[q] = (c < C) ? x[c] : 0.f; s += v[q]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int c = lane + 64 * q; if (c < C) { const float d = v[q] - mean; ss += d * d; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float rstd = 1.0f / sqrtf(ss / (float)C + GENIE_LN_EPS);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int c = lane + 64 * q; if (c < C) out[(size_t)row * C + c] = (v[q] - mean) * rstd * g[c] + bta[c]; }
+}
+
+// ---------------------------------------------------------------------------
+// IPA, activations -> attention operands
+// (modules/invariant_point_attention.py:124-174).  proj row layout:
+//   [ q (H*C) | kv (H*2C: per head k then v) | q_pts (3 blocks of H*Pq)
+//     | kv_pts (3 blocks of H*(Pq+Pv)) ].
+// Points are moved to the global frame (T.apply, affine_utils.py:118-121).
+// Keys go out j-contiguous (kT, kpT) so the logits pass reads them coalesced.
+// ---------------------------------------------------------------------------
+__global__ void k_ipa_prep(const float* __restrict__ proj, int ldp, const float* __restrict__ rots, const float* __restrict__ trans,
+                           float* __restrict__ kT, float* __restrict__ v, float* __restrict__ qp, float* __restrict__ kpT,
+                           float* __restrict__ vp, int N, int H, int C, int Pq, int Pv) {
+    const int row = blockIdx.x, b = row / N, n = row % N;
+    const float* pr = proj + (size_t)row * ldp;
+    const float* R = rots + (size_t)row * 9;
+    const float* t = trans + (size_t)row * 3;
+    const int HC = H * C, oq = 0, okv = HC, oqp = 3 * HC, okp = 3 * HC + 3 * H * Pq;
+    (void)oq;
+    for (int u = threadIdx.x; u < HC; u += blockDim.x) {
+        const int hh = u / C, c = u % C;
+        kT[(((size_t)b * H + hh) * C + c) * N + n] = pr[okv + hh * 2 * C + c];
+        v[(size_t)row * HC + u] = pr[okv + hh * 2 * C + C + c];
+    }
+    const int nq = H * Pq, nkv = H * (Pq + Pv);
+    for (int u = threadIdx.x; u < nq + nkv; u += blockDim.x) {
+        const bool isq = u < nq;
+        const int idx = isq ? u : u - nq;
+        const int blk = isq ? nq : nkv;
+        const float* src = pr + (isq ? oqp : okp);
+        const float x = src[idx], y = src[blk + idx], zc = src[2 * blk + idx];
+        const float gx = R[0] * x + R[1] * y + R[2] * zc + t[0];
+        const float gy = R[3] * x + R[4] * y + R[5] * zc + t[1];
+        const float gz = R[6] * x + R[7] * y + R[8] * zc + t[2];
+        if (isq) {
+            float* d = qp + ((size_t)row * nq + idx) * 3;
+            d[0] = gx; d[1] = gy; d[2] = gz;
+        } else {
+            const int hh = idx / (Pq + Pv), pp = idx % (Pq + Pv);
+            if (pp < Pq) {
+                float* d = kpT + ((((size_t)b * H + hh) * Pq + pp) * 3) * N + n;
+                d[0] = gx; d[N] = gy; d[2 * N] = gz;
+            } else {
+                float* d = vp + (((size_t)row * H + hh) * Pv + (pp - Pq)) * 3;
+                d[0] = gx; d[1] = gy; d[2] = gz;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// IPA attention core, one work-group per query residue (b, i)
+// (modules/invariant_point_attention.py:181-249):
+//   logit[h][j] = q.k/sqrt(3C) + sqrt(1/3) bias + (-1/2) softplus(g_h) wc sum_p |qp - kp|^2 + 1e5 (m_i m_j - 1)
+//   a = softmax_j;  o = a v;  o_pt = R_i^T (a v_pts - t_i);  |o_pt|;  o_pair = a z_i.
+// The p row (N x 128 fp32) is streamed exactly once, 512 B per row per wave
+// half; everything else is L2 resident.  Output: the linear_out input row
+//   [ o | o_pt.x | o_pt.y | o_pt.z | |o_pt| | o_pair ].
+// Dynamic LDS: att[H][N] | red[8][H][128] (aliased with q/qp scratch).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ipa_attn(const float* __restrict__ proj, int ldp, const float* __restrict__ kT,
+                                                  const float* __restrict__ v, const float* __restrict__ qp,
+                                                  const float* __restrict__ kpT, const float* __restrict__ vp,
+                                                  const float* __restrict__ bias, const float* __restrict__ z,
+                                                  const float* __restrict__ rots, const float* __restrict__ trans,
+                                                  const float* __restrict__ rmask, const float* __restrict__ head_w,
+                                                  float* __restrict__ cat, int B, int N, int H, int C, int Pq, int Pv,
+                                                  int c_p, int layer) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* att = sm;                       // [H][N]
+    float* scr = sm + H * N;               // scratch: q[H*C] | qpt[H*Pq*3] | hw[H] ; later red[8][H][c_p]
+    float* opt = scr + 8 * H * c_p;        // o_pt global-frame accumulators [H*Pv*3]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.x, b = row / N, i = row % N;
+    const int HC = H * C, nqp = H * Pq * 3;
+    float* sq = scr;
+    float* sqp = scr + HC;
+    float* shw = sqp + nqp;
+    for (int u = tid; u < HC; u += 256) sq[u] = proj[(size_t)row * ldp + u];
+    for (int u = tid; u < nqp; u += 256) sqp[u] = qp[(size_t)row * nqp + u];
+    if (tid < H) {
+        const float g = head_w[tid];
+        const float sp = (g > 20.f) ? g : log1pf(expf(g));          // nn.Softplus (beta 1, threshold 20)
+        shw[tid] = sp * sqrtf(1.0f / (3.0f * ((float)Pq * 9.0f / 2.0f)));
+    }
+    __syncthreads();
+    const float s_qk = sqrtf(1.0f / (3.0f * (float)C)), s_b = sqrtf(1.0f / 3.0f);
+    const float mi = rmask[row];
+    for (int j = tid; j < N; j += 256) {
+        const float sqm = 1e5f * (mi * rmask[b * N + j] - 1.0f);
+        for (int hh = 0; hh < H; ++hh) {
+            const float* kc = kT + (((size_t)b * H + hh) * C) * N + j;
+            float qk = 0.f;
+            for (int c = 0; c < C; ++c) qk += sq[hh * C + c] * kc[(size_t)c * N];
+            float a = qk * s_qk;
+            a += s_b * bias[((((size_t)layer * H + hh) * B + b) * N + i) * N + j];
+            const float* kp = kpT + ((((size_t)b * H + hh) * Pq) * 3) * N + j;
+            float pt = 0.f;
+            for (int pp = 0; pp < Pq; ++pp) {
+                const float dx = sqp[(hh * Pq + pp) * 3 + 0] - kp[(size_t)(pp * 3 + 0) * N];
+                const float dy = sqp[(hh * Pq + pp) * 3 + 1] - kp[(size_t)(pp * 3 + 1) * N];
+                const float dz = sqp[(hh * Pq + pp) * 3 + 2] - kp[(size_t)(pp * 3 + 2) * N];
+                pt += ((dx * dx + dy * dy) + dz * dz) * shw[hh];
+            }
+            a += pt * (-0.5f);
+            a += sqm;
+            att[hh * N + j] = a;
+        }
+    }
+    __syncthreads();
+    // softmax over j, one wave per head (round-robin)
+    for (int hh = wave; hh < H; hh += 4) {
+        float* ar = att + hh * N;
+        float mx = -3.0e38f;
+        for (int j = lane; j < N; j += 64) mx = fmaxf(mx, ar[j]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float s = 0.f;
+        for (int j = lane; j < N; j += 64) { const float e = expf(ar[j] - mx); ar[j] = e; s += e; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        for (int j = lane; j < N; j += 64) ar[j] = ar[j] / s;
+    }
+    __syncthreads();
+    float* crow = cat + (size_t)row * (HC + H * Pv * 4 + H * c_p);
+    // o (HC outputs) and o_pt (H*Pv*3 outputs, global frame)
+    const int npt = H * Pv * 3;
+    for (int u = tid; u < HC + npt; u += 256) {
+        float acc = 0.f;
+        if (u < HC) {
+            const float* ar = att + (u / C) * N;
+            const float* vv = v + (size_t)b * N * HC + u;
+            for (int j = 0; j < N; ++j) acc += ar[j] * vv[(size_t)j * HC];
+            crow[u] = acc;
+        } else {
+            const int w = u - HC;
+            const float* ar = att + (w / (Pv * 3)) * N;
+            const float* vv = vp + (size_t)b * N * npt + w;
+            for (int j = 0; j < N; ++j) acc += ar[j] * vv[(size_t)j * npt];
+            opt[w] = acc;
+        }
+    }
+    // o_pair: thread = (channel quad, j-group); 8 j-groups reduced through LDS
+    {
+        const int nq4 = c_p >> 2;                 // 32 float4 per row
+        const int c4 = tid % nq4, jg = tid / nq4; // jg in [0, 8)
+        constexpr int HMAX = 16;
+        float4 acc[HMAX];
+#pragma unroll
+        for (int hh = 0; hh < HMAX; ++hh) acc[hh] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* zr = z + ((size_t)row * N) * c_p + c4 * 4;
+        for (int j = jg; j < N; j += 8) {
+            const float4 zz = *reinterpret_cast<const float4*>(zr + (size_t)j * c_p);
+#pragma unroll
+            for (int hh = 0; hh < HMAX; ++hh) {
+                if (hh < H) {
+                    const float a = att[hh * N + j];
+                    acc[hh].x += a * zz.x; acc[hh].y += a * zz.y; acc[hh].z += a * zz.z; acc[hh].w += a * zz.w;
+                }
+            }
+        }
+        __syncthreads();     // q/qp scratch is dead, o/o_pt loops are done: reuse scr as red
+#pragma unroll
+        for (int hh = 0; hh < HMAX; ++hh)
+            if (hh < H) *reinterpret_cast<float4*>(scr + ((size_t)jg * H + hh) * c_p + c4 * 4) = acc[hh];
+    }
+    __syncthreads();
+    {
+        float* op = crow + HC + H * Pv * 4;
+        const int tot = H * c_p;
+        for (int u = tid; u < tot; u += 256) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) s += scr[(size_t)g * tot + u];
+            op[u] = s;
+        }
+    }
+    // o_pt -> local frame (T.invert_apply, affine_utils.py:123-126), norms
+    {
+        const int np = H * Pv;
+        const float* R = rots + (size_t)row * 9;
+        const float* t = trans + (size_t)row * 3;
+        for (int u = tid; u < np; u += 256) {
+            const float x = opt[u * 3 + 0] - t[0], y = opt[u * 3 + 1] - t[1], zc = opt[u * 3 + 2] - t[2];
+            const float lx = R[0] * x + R[3] * y + R[6] * zc;
+            const float ly = R[1] * x + R[4] * y + R[7] * zc;
+            const float lz = R[2] * x + R[5] * y + R[8] * zc;
+            crow[HC + u] = lx;
+            crow[HC + np + u] = ly;
+            crow[HC + 2 * np + u] = lz;
+            crow[HC + 3 * np + u] = sqrtf(((lx * lx + ly * ly) + lz * lz) + 1e-8f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Backbone update + frame composition (modules/backbone_update.py:40-66,
+// affine_utils.py:109-116,299-334), one wave per residue:
+//   [b c d | t] = W s + bias; q = (1,b,c,d)/sqrt(1+b^2+c^2+d^2);
+//   R <- R R(q);  t <- R t_upd + t.       Last layer also writes
+//   z = trans_in - t / rescale (model/model.py:184-187).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bb_update(const float* __restrict__ s, int c_s, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, float* __restrict__ rots,
+                                                   float* __restrict__ trans, int M, const float* __restrict__ trans_in,
+                                                   float* __restrict__ z_out, float inv_rescale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int c = lane; c < c_s; c += 64) {
+        const float x = s[(size_t)row * c_s + c];
+#pragma unroll
+        for (int o = 0; o < 6; ++o) acc[o] += x * w[o * c_s + c];
+    }
+#pragma unroll
+    for (int o = 0; o < 6; ++o) {
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) acc[o] += __shfl_xor(acc[o], sft);
+        acc[o] += bias[o];
+    }
+    if (lane == 0) {
+        const float qb = acc[0], qc = acc[1], qd = acc[2];
+        const float den = sqrtf(((qb * qb + qc * qc) + qd * qd) + 1.0f);
+        const float a = 1.0f / den, bq = qb / den, c = qc / den, d = qd / den;
+        float U[9];
+        U[0] = a * a + bq * bq - c * c - d * d; U[1] = 2 * bq * c - 2 * a * d;          U[2] = 2 * bq * d + 2 * a * c;
+        U[3] = 2 * bq * c + 2 * a * d;          U[4] = a * a - bq * bq + c * c - d * d; U[5] = 2 * c * d - 2 * a * bq;
+        U[6] = 2 * bq * d - 2 * a * c;          U[7] = 2 * c * d + 2 * a * bq;          U[8] = a * a - bq * bq - c * c + d * d;
+        float* R = rots + (size_t)row * 9;
+        float* t = trans + (size_t)row * 3;
+        float Rn[9], r[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) r[k] = R[k];
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+            for (int y = 0; y < 3; ++y) Rn[x * 3 + y] = r[x * 3 + 0] * U[0 * 3 + y] + r[x * 3 + 1] * U[1 * 3 + y] + r[x * 3 + 2] * U[2 * 3 + y];
+        const float tx = r[0] * acc[3] + r[1] * acc[4] + r[2] * acc[5] + t[0];
+        const float ty = r[3] * acc[3] + r[4] * acc[4] + r[5] * acc[5] + t[1];
+        const float tz = r[6] * acc[3] + r[7] * acc[4] + r[8] * acc[5] + t[2];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = Rn[k];
+        t[0] = tx; t[1] = ty; t[2] = tz;
+        if (z_out) {
+            z_out[(size_t)row * 3 + 0] = trans_in[(size_t)row * 3 + 0] - tx * inv_rescale;
+            z_out[(size_t)row * 3 + 1] = trans_in[(size_t)row * 3 + 1] - ty * inv_rescale;
+            z_out[(size_t)row * 3 + 2] = trans_in[(size_t)row * 3 + 2] - tz * inv_rescale;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Reverse-loop update + Frenet frames, one work-group per structure
+// (sampler/base.py:249-282, utils/geo_utils.py:21-85).
+//   mode 0: frames of `trans` only.
+//   mode 1: trans <- ((trans - w_z z)/sqrt(alpha_t)) * mask [+ scale sqrt(beta_t) eps, * mask], then frames.
+// Chain starts/ends copy their neighbour exactly as the reference's two
+// sequential fix-up loops do (including what they do for consecutive chain ends).
+// Dynamic LDS: x[N][3] | tv[N][3] | base[N][9] | st1[N][9] | flags.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_p_sample_frenet(int mode, float* __restrict__ trans, float* __restrict__ rots,
+                                                         const float* __restrict__ z, const float* __restrict__ eps,
+                                                         const int32_t* __restrict__ rmask, const int32_t* __restrict__ cidx,
+                                                         int N, float alpha, float sqrt_alpha, float somac, float sqrt_beta,
+                                                         float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* x = sm;
+    float* tv = x + 3 * N;
+    float* base = tv + 3 * N;
+    float* st1 = base + 9 * N;
+    __shared__ int s_len;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float* tr = trans + (size_t)b * N * 3;
+    if (tid == 0) s_len = 0;
+    __syncthreads();
+    int cnt = 0;
+    for (int n = tid; n < N; n += 256) cnt += rmask[b * N + n];
+    atomicAdd(&s_len, cnt);
+    if (mode == 1) {
+        const float w_z = (1.0f - alpha) / somac;
+        const float inv_sa = 1.0f / sqrt_alpha;
+        for (int u = tid; u < 3 * N; u += 256) {
+            const float m = (float)rmask[b * N + u / 3];
+            float v = inv_sa * (tr[u] - w_z * z[(size_t)b * N * 3 + u]);
+            v = v * m;
+            if (eps) { v = v + scale * sqrt_beta * eps[(size_t)b * N * 3 + u]; v = v * m; }
+            x[u] = v;
+            tr[u] = v;
+        }
+    } else {
+        for (int u = tid; u < 3 * N; u += 256) x[u] = tr[u];
+    }
+    __syncthreads();
+    const int len = s_len;
+    for (int n = tid; n < N - 1; n += 256) {
+        const float dx = x[3 * n + 3] - x[3 * n], dy = x[3 * n + 4] - x[3 * n + 1], dz = x[3 * n + 5] - x[3 * n + 2];
+        const float nr = sqrtf(1e-10f + ((dx * dx + dy * dy) + dz * dz));
+        tv[3 * n] = dx / nr; tv[3 * n + 1] = dy / nr; tv[3 * n + 2] = dz / nr;
+    }
+    __syncthreads();
+    for (int n = tid; n < N; n += 256) {
+        float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+        // rots_[1:len-1] = tbn[0:len-2]; tbn[m] built from t[m], t[m+1]
+        if (n >= 1 && n < len - 1) {
+            const int m = n - 1;
+            const float ax = tv[3 * m], ay = tv[3 * m + 1], az = tv[3 * m + 2];
+            const float bx = tv[3 * m + 3], by = tv[3 * m + 4], bz = tv[3 * m + 5];
+            float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+            const float nr = sqrtf(1e-10f + ((cx * cx + cy * cy) + cz * cz));
+            cx /= nr; cy /= nr; cz /= nr;
+            const float nx = cy * bz - cz * by, ny = cz * bx - cx * bz, nz = cx * by - cy * bx;
+            R[0] = bx; R[1] = cx; R[2] = nx;
+            R[3] = by; R[4] = cy; R[5] = ny;
+            R[6] = bz; R[7] = cz; R[8] = nz;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) base[9 * n + k] = R[k];
+    }
+    __syncthreads();
+    const int32_t* ch = cidx + b * N;
+    // start-of-chain pass: every read sees the pre-pass value (the reference walks j upward and reads j+1)
+    for (int n = tid; n < N; n += 256) {
+        int srcn = n;
+        if (n < len && (n == 0 || ch[n] != ch[n - 1])) srcn = n + 1;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) st1[9 * n + k] = (srcn < N) ? base[9 * srcn + k] : ((k % 4 == 0) ? 1.f : 0.f);
+    }
+    __syncthreads();
+    // end-of-chain pass: sequential dependence j <- j-1 resolved by walking back over consecutive ends
+    float* ro = rots + (size_t)b * N * 9;
+    for (int n = tid; n < N; n += 256) {
+        int k = n;
+        if (n < len) {
+            while (k >= 0 && (k == len - 1 || ch[k] != ch[k + 1])) --k;
+            if (k < 0) k = N - 1;        // python's rots_[-1]
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) ro[9 * n + q] = st1[9 * k + q];
+    }
+}
+
+__global__ void k_fill_i32(int32_t* p, int n, int v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+__global__ void k_scale_copy(const float* __restrict__ in, float* __restrict__ out, int n, float s) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] * s;
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+void launch_single_input(genie_ctx* h, hipStream_t st, const int32_t* timesteps) {
+    ProfScope ps(h, st, KC_SINGLE_INPUT);
+    const genie_dims_t& d = h->d;
+    const int ldx = (d.c_pos_emb + d.c_chain_emb + d.c_timestep_emb + 23 + 7) / 8 * 8;
+    hipLaunchKernelGGL(k_single_input, dim3(h->B * h->N), dim3(256), 0, st, h->xsingle, ldx, h->pos_tab, h->n_pos, d.c_pos_emb,
+                       h->chain_tab, h->n_chain, d.c_chain_emb, h->t_tab, d.c_timestep_emb, timesteps, h->f_ridx, h->f_cidx,
+                       h->f_aatype, h->f_fsm, h->f_ifm, h->N, d.n_timestep);
+}
+
+void launch_gemm_rows(genie_ctx* h, hipStream_t st, const float* A, int lda, int M, int K, const float* Wp, int Nout,
+                      const float* bias, const float* res, int ldr, const float* rowmask, int relu, float* out, int ldo) {
+    ProfScope ps(h, st, KC_GEMM_ROWS);
+    dim3 grid((M + 31) / 32, (Nout + 127) / 128);
+    hipLaunchKernelGGL(k_gemm_rows, grid, dim3(256), 0, st, A, lda, M, K, Wp, Nout, bias, res, ldr, rowmask, relu, out, ldo);
+}
+
+void launch_layernorm_rows(genie_ctx* h, hipStream_t st, const float* in, float* out, int M, int C, const float* g,
+                           const float* b) {
+    ProfScope ps(h, st, KC_LAYERNORM);
+    hipLaunchKernelGGL(k_layernorm_rows, dim3((M + 3) / 4), dim3(256), 0, st, in, out, M, C, g, b);
+}
+
+void launch_ipa_prep(genie_ctx* h, hipStream_t st) {
+    ProfScope ps(h, st, KC_IPA_PREP);
+    const genie_dims_t& d = h->d;
+    const int ldp = d.n_head_ipa * (3 * d.c_hidden_ipa + 3 * d.n_qk_point + 3 * (d.n_qk_point + d.n_v_point));
+    hipLaunchKernelGGL(k_ipa_prep, dim3(h->B * h->N), dim3(256), 0, st, h->proj, ldp, h->rots_w, h->trans_w, h->kT, h->v, h->qp,
+                       h->kpT, h->vp, h->N, d.n_head_ipa, d.c_hidden_ipa, d.n_qk_point, d.n_v_point);
+}
+
+size_t ipa_attn_lds(const genie_dims_t& d, int N) {
+    return ((size_t)d.n_head_ipa * N + 8 * d.n_head_ipa * d.c_p + d.n_head_ipa * d.n_v_point * 3) * sizeof(float);
+}
+
+void launch_ipa_attn(genie_ctx* h, hipStream_t st, int layer, const float* head_w) {
+    ProfScope ps(h, st, KC_IPA_ATTN);
+    const genie_dims_t& d = h->d;
+    const int ldp = d.n_head_ipa * (3 * d.c_hidden_ipa + 3 * d.n_qk_point + 3 * (d.n_qk_point + d.n_v_point));
+    hipLaunchKernelGGL(k_ipa_attn, dim3(h->B * h->N), dim3(256), ipa_attn_lds(d, h->N), st, h->proj, ldp, h->kT, h->v, h->qp,
+                       h->kpT, h->vp, h->ipa_bias, h->p, h->rots_w, h->trans_w, h->rmaskf, head_w, h->cat, h->B, h->N,
+                       d.n_head_ipa, d.c_hidden_ipa, d.n_qk_point, d.n_v_point, d.c_p, layer);
+}
+
+void launch_bb_update(genie_ctx* h, hipStream_t st, const StructLayerW& w, const float* trans_in, float* z_out) {
+    ProfScope ps(h, st, KC_BB_UPDATE);
+    const int M = h->B * h->N;
+    hipLaunchKernelGGL(k_bb_update, dim3((M + 3) / 4), dim3(256), 0, st, h->s, h->d.c_s, w.bb_w, w.bb_b, h->rots_w, h->trans_w,
+                       M, trans_in, z_out, 1.0f / h->d.rescale);
+}
+
+void launch_frenet(genie_ctx* h, hipStream_t st, int mode, int step, float scale, float* trans, float* rots, const float* z,
+                   const float* eps) {
+    ProfScope ps(h, st, KC_P_SAMPLE);
+    float al = 1.f, sa = 1.f, so = 1.f, sb = 0.f;
+    if (mode == 1) {
+        const int T1 = h->d.n_timestep + 1;
+        al = h->sched_host[0 * T1 + step];
+        sa = h->sched_host[1 * T1 + step];
+        so = h->sched_host[2 * T1 + step];
+        sb = h->sched_host[3 * T1 + step];
+    }
+    const size_t lds = (size_t)(3 + 3 + 9 + 9) * h->N * sizeof(float);
+    hipLaunchKernelGGL(k_p_sample_frenet, dim3(h->B), dim3(256), lds, st, mode, trans, rots, z, eps, h->f_rmask, h->f_cidx, h->N,
+                       al, sa, so, sb, scale);
+}
+
+void launch_fill_i32(genie_ctx* h, hipStream_t st, int32_t* p, int n, int v) {
+    ProfScope ps(h, st, KC_MISC);
+    hipLaunchKernelGGL(k_fill_i32, dim3((n + 255) / 256), dim3(256), 0, st, p, n, v);
+}
+
+void launch_scale_copy(genie_ctx* h, hipStream_t st, const float* in, float* out, int n, float s) {
+    ProfScope ps(h, st, KC_MISC);
+    hipLaunchKernelGGL(k_scale_copy, dim3((n + 255) / 256), dim3(256), 0, st, in, out, n, s);
+}
+
+void single_kernels_init(const genie_dims_t& d, int n_max) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)ipa_attn_lds(d, n_max));
+}

@@ -1,0 +1,144 @@
+"""GenieEngine: one libgenie_hip handle bound to one GPU.
+
+PyTorch is plumbing here (device buffers and the current stream); every
+tensor op of the denoising path runs inside the HIP library.
+"""
+import ctypes as C
+
+import torch
+
+from . import capi, pack
+
+_FEATURE_DTYPES = {
+    'aatype': torch.int32, 'atom_positions': torch.float32, 'residue_mask': torch.int32,
+    'residue_index': torch.int32, 'chain_index': torch.int32,
+    'fixed_sequence_mask': torch.bool, 'fixed_structure_mask': torch.bool, 'interface_mask': torch.bool,
+}
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class GenieEngine:
+    def __init__(self, dims, state_dict, device='cuda:0', n_pos=None, n_chain=None):
+        self.lib = capi.load_library()
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise capi.GenieError('GenieEngine needs a GPU device (there is no CPU path)')
+        if not torch.cuda.is_available():
+            raise capi.GenieError('no HIP device visible to PyTorch')
+        self.dims = {k: dims[k] for k in pack.DIM_KEYS}
+        cd = capi.GenieDims(**self.dims)
+        self._h = C.c_void_p()
+        rc = self.lib.genie_create(C.byref(cd), self.device.index or 0, C.byref(self._h))
+        capi.check(None, rc, 'genie_create')
+        blob = pack.flatten_state_dict(state_dict, self.dims)
+        assert blob.numel() == self.lib.genie_weight_count(C.byref(cd))
+        capi.check(self._h, self.lib.genie_load_weights(self._h, _ptr(blob), blob.numel()), 'genie_load_weights')
+        self.n_pos = int(n_pos or max(self.dims['max_n_res'], 1))
+        self.n_chain = int(n_chain or max(self.dims['max_n_chain'], 8))
+        self.schedule = pack.schedule_tensors(self.dims['n_timestep'])
+        pos = pack.sinusoidal_table(self.n_pos, self.dims['max_n_res'], self.dims['c_pos_emb'])
+        chn = pack.sinusoidal_table(self.n_chain, self.dims['max_n_chain'], self.dims['c_chain_emb'])
+        tt = pack.sinusoidal_table(self.dims['n_timestep'] + 1, self.dims['n_timestep'], self.dims['c_timestep_emb'])
+        sb = pack.schedule_block(self.schedule)
+        capi.check(self._h, self.lib.genie_set_tables(self._h, _ptr(pos), self.n_pos, _ptr(chn), self.n_chain,
+                                                      _ptr(tt), _ptr(sb)), 'genie_set_tables')
+        self.B = self.N = None
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self.lib.genie_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, t, dtype):
+        return t.to(device=self.device, dtype=dtype).contiguous()
+
+    def bind_features(self, features):
+        """features: the reference's batched feature dict (torch tensors)."""
+        f = {k: self._dev(features[k], dt) for k, dt in _FEATURE_DTYPES.items()}
+        B, N = f['residue_mask'].shape
+        if int(f['residue_index'].max()) >= self.n_pos or int(f['chain_index'].max()) >= self.n_chain:
+            raise capi.GenieError('residue_index / chain_index exceed the uploaded encoding tables')
+        gf = capi.GenieFeatures(**{k: f[k].data_ptr() for k in _FEATURE_DTYPES})
+        with torch.cuda.device(self.device):
+            rc = self.lib.genie_prepare_features(self._h, self._stream(), B, N, C.byref(gf))
+        capi.check(self._h, rc, 'genie_prepare_features')
+        self._bound = f           # keep alive until the async copies ran
+        self.B, self.N = B, N
+
+    def frenet(self, trans):
+        trans = self._dev(trans, torch.float32)
+        rots = torch.empty(self.B, self.N, 3, 3, device=self.device)
+        capi.check(self._h, self.lib.genie_frenet(self._h, self._stream(), _ptr(trans), _ptr(rots)), 'genie_frenet')
+        return rots
+
+    def denoise(self, trans, rots, timesteps, quat_codes=None, taps=()):
+        """Denoiser.forward.  Returns {'z': ..., <tap>: ...}."""
+        B, N = self.B, self.N
+        trans = self._dev(trans, torch.float32)
+        rots = self._dev(rots, torch.float32)
+        ts = self._dev(timesteps, torch.int32)
+        codes = self._dev(quat_codes, torch.int8) if quat_codes is not None else None
+        z = torch.empty(B, N, 3, device=self.device)
+        shapes = {'s': (B, N, self.dims['c_s']), 'p': (B, N, N, self.dims['c_p']), 's_final': (B, N, self.dims['c_s']),
+                  'rots_out': (B, N, 3, 3), 'trans_out': (B, N, 3), 'p_init': (B, N, N, self.dims['c_p']),
+                  'p_layer0': (B, N, N, self.dims['c_p'])}
+        out = {k: torch.empty(shapes[k], device=self.device) for k in taps}
+        ct = capi.GenieTaps(**{k: v.data_ptr() for k, v in out.items()})
+        rc = self.lib.genie_denoise(self._h, self._stream(), _ptr(trans), _ptr(rots), _ptr(ts), _ptr(codes), _ptr(z),
+                                    C.byref(ct) if taps else None)
+        capi.check(self._h, rc, 'genie_denoise')
+        out['z'] = z
+        return out
+
+    def p_sample(self, step, scale, trans, z, eps):
+        """In place on `trans`; returns the new frames."""
+        rots = torch.empty(self.B, self.N, 3, 3, device=self.device)
+        rc = self.lib.genie_p_sample(self._h, self._stream(), int(step), float(scale), _ptr(trans), _ptr(rots), _ptr(z),
+                                     _ptr(eps))
+        capi.check(self._h, rc, 'genie_p_sample')
+        return rots
+
+    def sample_loop(self, noise, scale, quat_codes=None, first_step=None, last_step=1, state=None, record=False):
+        """noise [T,B,N,3] on device.  Returns (trans, rots, record or None)."""
+        T = self.dims['n_timestep']
+        first_step = T if first_step is None else first_step
+        noise = self._dev(noise, torch.float32)
+        n_it = first_step - last_step + 1
+        codes = self._dev(quat_codes, torch.int8) if quat_codes is not None else None
+        if state is None:
+            trans = torch.empty(self.B, self.N, 3, device=self.device)
+            rots = torch.empty(self.B, self.N, 3, 3, device=self.device)
+        else:
+            trans, rots = state
+        rec = torch.empty(n_it, self.B, self.N, 3, device=self.device) if record else None
+        rc = self.lib.genie_sample_loop(self._h, self._stream(), float(scale), _ptr(noise), _ptr(codes), first_step,
+                                        last_step, _ptr(trans), _ptr(rots), _ptr(rec))
+        capi.check(self._h, rc, 'genie_sample_loop')
+        return trans, rots, rec
+
+    # ------------------------------------------------------------------
+    def profile(self, enable):
+        self.lib.genie_profile_enable(self._h, 1 if enable else 0)
+
+    def profile_read(self):
+        names = (C.c_char_p * 32)()
+        ms = (C.c_double * 32)()
+        cnt = (C.c_int64 * 32)()
+        n = self.lib.genie_profile_read(self._h, names, ms, cnt, 32)
+        return {names[i].decode(): (ms[i], cnt[i]) for i in range(n)}
+
+    def workspace_bytes(self):
+        return int(self.lib.genie_workspace_bytes(self._h))

@@ -1,0 +1,170 @@
+/*
+ * genie_hip.h -- C ABI of libgenie_hip.so: the MI355X (gfx950) denoising path
+ * of Genie 2 (marvinli00/genie2), hand-written HIP behind plain pointers.
+ *
+ * The reference has no FFI of its own: its seam is the Python
+ * call `self.model.model(ts, timesteps, features)['z']` inside the reverse
+ * loop.  Each entry point below names the reference code it replaces
+ * (paths relative to the reference root).
+ *
+ * Conventions
+ *   - return 0 = ok, < 0 = error (GENIE_E_*); text via genie_last_error().
+ *     No C++ exception crosses this boundary.
+ *   - the caller owns every tensor buffer passed in (device memory on the
+ *     handle's device unless marked HOST; contiguous; fp32 / int32 / uint8);
+ *     the library owns the handle, packed weights, tables and workspace.
+ *   - all device work is enqueued on the caller's stream and is asynchronous;
+ *     no entry point except genie_create / genie_load_weights /
+ *     genie_set_tables / genie_profile_read synchronises.
+ *   - a handle is single-threaded: one per (process, device), matching the
+ *     reference's one-process-per-device launcher
+ *     (genie/utils/multiprocessor.py:84-96).
+ */
+#ifndef GENIE_HIP_H
+#define GENIE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GENIE_OK            0
+#define GENIE_E_ARG        -1   /* bad argument / unsupported shape */
+#define GENIE_E_STATE      -2   /* call order (weights/tables/features missing) */
+#define GENIE_E_HIP        -3   /* HIP runtime error */
+#define GENIE_E_NOMEM      -4
+
+typedef struct genie_ctx* genie_handle_t;
+typedef void* genie_stream_t;           /* hipStream_t */
+
+/* Mirrors the keys of Config.model / .diffusion / .io that
+ * Denoiser(**config.model, n_timestep, max_n_res, max_n_chain) consumes
+ * (genie/config.py:36-80, genie/diffusion/ddpm.py:26-31). */
+typedef struct {
+    int32_t c_s, c_p;
+    int32_t c_pos_emb, c_chain_emb, c_timestep_emb;
+    int32_t relpos_k;
+    int32_t template_dist_n_bin;
+    float   template_dist_min, template_dist_step;
+    int32_t n_pair_transform_layer, c_hidden_mul, pair_transition_n;
+    int32_t n_structure_layer, n_structure_block;
+    int32_t c_hidden_ipa, n_head_ipa, n_qk_point, n_v_point;
+    float   rescale;
+    int32_t n_timestep, max_n_res, max_n_chain;
+} genie_dims_t;
+
+/* The tensors of the reference's 12-key feature dict the denoiser reads
+ * (genie/utils/feat_utils.py:304-321; model/*.py).  bool tensors are passed
+ * as their 1-byte storage. */
+typedef struct {
+    const int32_t* aatype;               /* [B,N,20] */
+    const float*   atom_positions;       /* [B,N,3]  motif coordinates */
+    const int32_t* residue_mask;         /* [B,N]    */
+    const int32_t* residue_index;        /* [B,N]    */
+    const int32_t* chain_index;          /* [B,N]    */
+    const uint8_t* fixed_sequence_mask;  /* [B,N]    */
+    const uint8_t* fixed_structure_mask; /* [B,N,N]  */
+    const uint8_t* interface_mask;       /* [B,N]    */
+} genie_features_t;
+
+/* Optional stage outputs of one denoiser call (any pointer may be NULL).
+ * They are the other entries of the dict Denoiser.forward returns
+ * (genie/model/model.py:186-192) plus two intermediate taps for tests. */
+typedef struct {
+    float* s;          /* [B,N,c_s]      's'  (single feature net output)      */
+    float* p;          /* [B,N,N,c_p]    'p'  (pair transform net output)      */
+    float* s_final;    /* [B,N,c_s]      'states'[-1]                          */
+    float* rots_out;   /* [B,N,3,3]      'ts'.rots                             */
+    float* trans_out;  /* [B,N,3]        'ts'.trans                            */
+    float* p_init;     /* [B,N,N,c_p]    pair feature net output (test tap)    */
+    float* p_layer0;   /* [B,N,N,c_p]    after pair transform layer 0 (tap)    */
+} genie_taps_t;
+
+/* ---- lifetime ---------------------------------------------------------- */
+
+/* Replaces Denoiser.__init__ (genie/model/model.py:20-123). */
+int genie_create(const genie_dims_t* dims, int device, genie_handle_t* out);
+void genie_destroy(genie_handle_t h);
+const char* genie_last_error(genie_handle_t h);   /* h may be NULL: last create error */
+
+/* Number of fp32 values genie_load_weights expects for these dims. */
+size_t genie_weight_count(const genie_dims_t* dims);
+
+/* Replaces load_state_dict: `blob` (HOST) is every tensor of
+ * Denoiser.state_dict() in its own order (checkpoint
+ * keys are these with a 'model.' prefix, genie/utils/model_io.py:159-173),
+ * each [out,in] row-major, concatenated.  Repacked into MFMA fragment order
+ * and uploaded. */
+int genie_load_weights(genie_handle_t h, const float* blob, size_t n_floats);
+
+/* Sinusoidal tables and the diffusion schedule, computed by the host with
+ * the reference's own expressions (genie/utils/encoding.py:5-25,
+ * genie/diffusion/ddpm.py:40-56) and uploaded once.  All HOST pointers.
+ *   pos_tab   [n_pos][c_pos_emb]      row v = encoding of residue_index v
+ *   chain_tab [n_chain][c_chain_emb]  row v = encoding of chain_index v
+ *   t_tab     [n_timestep+1][c_timestep_emb]
+ *   sched     [4][n_timestep+1] = alphas, sqrt_alphas,
+ *             sqrt_one_minus_alphas_cumprod, sqrt_betas */
+int genie_set_tables(genie_handle_t h, const float* pos_tab, int n_pos,
+                     const float* chain_tab, int n_chain,
+                     const float* t_tab, const float* sched);
+
+/* ---- per batch --------------------------------------------------------- */
+
+/* Binds a batch of features (device pointers are read now and copied into
+ * library-owned buffers) and computes the step-invariant pair terms
+ * (_relpos and the motif template: genie/model/pair_feature_net.py:134,
+ * 149-158,166-221).  Sizes the workspace for (B, N). */
+int genie_prepare_features(genie_handle_t h, genie_stream_t stream, int B, int N,
+                           const genie_features_t* feats);
+
+/* compute_frenet_frames (genie/utils/geo_utils.py:21-85) for the bound batch. */
+int genie_frenet(genie_handle_t h, genie_stream_t stream, const float* trans /*[B,N,3]*/,
+                 float* rots_out /*[B,N,3,3]*/);
+
+/* Denoiser.forward (genie/model/model.py:125-192): z_out[B,N,3].
+ * timesteps: device int32 [B].  quat_codes: optional device int8 [B,N,N]
+ * pinning the sign of each pair quaternion to the reference's eigh output
+ * (SURVEY.md hazard 1): 0 = canonical, else 1 + 2*m + neg = "component m has
+ * sign (neg ? - : +)". */
+int genie_denoise(genie_handle_t h, genie_stream_t stream,
+                  const float* trans, const float* rots, const int32_t* timesteps,
+                  const int8_t* quat_codes, float* z_out, const genie_taps_t* taps);
+
+/* One ancestral step of BaseSampler._sample (genie/sampler/base.py:249-282):
+ * trans <- ((trans - w_z z)/sqrt(alpha_t) * mask [+ scale sqrt(beta_t) eps]) * mask,
+ * then Frenet frames.  eps == NULL for step 1. */
+int genie_p_sample(genie_handle_t h, genie_stream_t stream, int step, float scale,
+                   float* trans_inout, float* rots_out, const float* z, const float* eps);
+
+/* The whole reverse loop (genie/sampler/base.py:227-282), device resident.
+ * noise [n_timestep][B,N,3]: noise[0] is the initial trans (base.py:227),
+ * noise[k] the draw of iteration k (steps T..2).  first_step/last_step allow a
+ * partial trajectory (T..1 for the full one); when first_step < T,
+ * trans_io/rots_io carry the state in.  quat_codes: NULL or
+ * [n_iterations][B,N,N].  record: NULL or [n_iterations][B,N,3], x after
+ * every iteration. */
+int genie_sample_loop(genie_handle_t h, genie_stream_t stream, float scale,
+                      const float* noise, const int8_t* quat_codes,
+                      int first_step, int last_step,
+                      float* trans_io, float* rots_io, float* record);
+
+/* ---- measurement ------------------------------------------------------- */
+
+/* Per-kernel-class HIP-event timing on the launch stream (bench.py roofline
+ * leg).  enable != 0 starts recording (adds event overhead: not for timed
+ * regions).  genie_profile_read synchronises and returns up to `cap` entries;
+ * returns the number of classes, names are static strings. */
+int genie_profile_enable(genie_handle_t h, int enable);
+int genie_profile_read(genie_handle_t h, const char** names, double* total_ms,
+                       int64_t* launches, int cap);
+
+/* Workspace bytes currently held (HBM layout report for DESIGN.md). */
+size_t genie_workspace_bytes(genie_handle_t h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
