@@ -1,0 +1,208 @@
+"""Headline benchmark: denoise-steps/sec at N=256, T=1000, batch=8 (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one iteration of the reverse loop (genie/sampler/base.py:239-282)
+over one batch of 8 structures: Denoiser.forward + posterior update + Frenet
+frames, all inside libgenie_hip (genie_sample_loop), inputs resident in HBM.
+Each rank runs its own replica with its own noise seed (structures shard across
+GPUs with no data-path collective); the only collectives are the timing
+barrier / max and a trivial all_gather of the final C-alpha coordinates.
+
+Rank 0 prints ONE JSON line.  `value` = batch-steps/s summed over all ranks
+(x8 = structure-steps/s, also reported).  `roofline` prices the dominant kernel
+class against the fp32 MFMA peak; `cpu_baseline` times the oracle (the CPU
+restatement of the reference) on this host for one step of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from genie2_amd import pack  # noqa: E402
+from genie2_amd.engine import GenieEngine  # noqa: E402
+from genie2_amd import features as F  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0
+
+
+def algorithmic_flops(dims, B, N):
+    """FLOP per launch of each MFMA kernel class."""
+    M = B * N * N
+    c = dims['c_p']
+    return {
+        'trimul_proj': 2.0 * M * c * 4 * dims['c_hidden_mul'],
+        'trimul_contract': 2.0 * B * dims['c_hidden_mul'] * N ** 3,
+        'trimul_out': 2.0 * M * c * c * 2,
+        'pair_transition': 2.0 * M * c * c * dims['pair_transition_n'] * 2,
+    }
+
+
+def step_flops(dims, B, N):
+    """Algorithmic FLOP per batch-step (2.17e12 at B=8, N=256)."""
+    c, L = dims['c_p'], dims['n_pair_transform_layer']
+    pair = B * N * N * L * (40 * c * c + 4 * N * c)
+    return pair + B * N * N * (8 * 7.9e3 + 38e3) + B * N * 27.9e6
+
+
+def host_cores():
+    """CPU cores this process may actually use: affinity, capped by the cgroup
+    quota (a GPU box exposes every core of the host but grants a share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    env = os.environ.get('GENIE_BENCH_CPU_THREADS')
+    if env:
+        n = int(env)
+    elif n > 64:
+        n = 16      # no quota visible on a many-core host: use the documented 1-GPU CPU share
+    return n
+
+
+def cpu_baseline(dims, B, N, seed):
+    """One step of the same workload through the oracle on the host cores."""
+    from oracle import genie_oracle as O
+    torch.set_num_threads(host_cores())
+    sd = pack.random_state_dict(dims, seed=0)
+    f = O.empty_features([N] * B)
+    g = torch.Generator().manual_seed(seed)
+    trans = torch.randn(B, N, 3, generator=g)
+    fr = O.prepare_features(f)
+    rots = O.compute_frenet_frames(trans, fr['chain_index'], fr['residue_mask'])
+    sched = O.setup_schedule(dims['n_timestep'])
+    step = dims['n_timestep']
+    ts = torch.full((B,), step, dtype=torch.int32)
+    t0 = time.time()
+    with torch.no_grad():
+        z = O.denoiser_forward(sd, dims, rots, trans, ts, f, 'eigh')['z']
+        O.p_sample_step(sched, step, 0.6, trans, z, torch.randn(B, N, 3, generator=g), fr)
+    dt = time.time() - t0
+    return {'value': 1.0 / dt, 'unit': 'batch-steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'1 reverse-loop step (denoiser + posterior + Frenet) at N={N}, batch={B}, fp32, '
+                      f'oracle/genie_oracle.py with torch.linalg.eigh quaternions, {dt:.1f} s wall'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--length', type=int, default=256)
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--profile-steps', type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    dist = world > 1
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if dist:
+        import torch.distributed as td
+        td.init_process_group('nccl', device_id=dev)
+
+    dims = dict(pack.BASE_DIMS)
+    B, N, T = args.batch, args.length, dims['n_timestep']
+    K, W = args.steps, args.warmup
+    assert K + W <= T, 'steps + warmup must fit in T'
+    eng = GenieEngine(dims, pack.random_state_dict(dims, seed=0), dev)
+    feats = F.convert_np_features_to_tensor(
+        F.batchify_np_features([F.create_empty_np_features([N]) for _ in range(B)]), dev)
+    eng.bind_features(feats)
+    g = torch.Generator().manual_seed(42 + rank)
+    P = max(1, args.profile_steps)
+    noise = torch.randn(K + W + 1 + P, B, N, 3, generator=g).to(dev)   # draws of iterations 0..K+W(+P) (base.py:227,269)
+
+    def barrier():
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize(dev)
+
+    state = None
+    if W > 0:
+        tr, ro, _ = eng.sample_loop(noise, 0.6, first_step=T, last_step=T - W + 1)
+        state = (tr, ro)
+    else:
+        tr = noise[0].clone()
+        state = (tr, eng.frenet(tr))
+    barrier()
+    t0 = time.perf_counter()
+    tr, ro, _ = eng.sample_loop(noise, 0.6, first_step=T - W, last_step=T - W - K + 1, state=state)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        td.all_reduce(tmax, op=td.ReduceOp.MAX)
+        dt = float(tmax.item())
+        gathered = [torch.empty_like(tr) for _ in range(world)]      # trivial result gather over xGMI
+        td.all_gather(gathered, tr)
+    finite = bool(torch.isfinite(tr).all().item())
+
+    out = None
+    if rank == 0:
+        value = K * world / dt
+        # per-kernel timing with HIP events on the launch stream (separate, untimed pass)
+        eng.profile(True)
+        s0 = T - W - K
+        if s0 - P < 1:
+            s0 = T
+        eng.sample_loop(noise, 0.6, first_step=s0, last_step=s0 - P + 1, state=(tr.clone(), ro.clone()))
+        torch.cuda.synchronize(dev)
+        eng.profile(False)
+        prof = eng.profile_read()
+        flops = algorithmic_flops(dims, B, N)
+        kern = {k: {'ms_per_launch': ms / max(cnt, 1), 'launches_per_step': cnt / P, 'ms_per_step': ms / P}
+                for k, (ms, cnt) in prof.items() if cnt}
+        dom = max((k for k in kern if k in flops), key=lambda k: kern[k]['ms_per_step'])
+        ach = flops[dom] / (kern[dom]['ms_per_launch'] * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                'avg_launch_ms': kern[dom]['ms_per_launch'], 'flop_per_launch': flops[dom]}
+        whole = step_flops(dims, B, N) * (K / dt) / 1e12
+        out = {
+            'metric': 'denoise-steps/sec (N=256, T=1000, batch=8)', 'value': value, 'unit': 'batch-steps/s',
+            'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': dt / K * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'unconditional N={N}, T={T}, batch={B} per GPU, random-init base Denoiser '
+                                   f'(15.7M params), scale=0.6, reverse-loop steps {T - W}..{T - W - K + 1}',
+                       'parallelism': f'replica per GPU x{world}, no data-path collective'},
+            'structure_steps_per_s': value * B,
+            'whole_step_tflops': whole, 'whole_step_frac_of_fp32_mfma_peak': whole / PEAK_FP32_MFMA_TFLOPS,
+            'finite': finite, 'roofline': roof,
+            'kernels': {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in kern.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(dims, B, N, 42)
+            out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+    if dist:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -7,6 +7,11 @@ it raises, loudly.
 import ctypes as C
 import os
 
+# PyTorch-ROCm bundles its own libamdhip64; it must be the HIP runtime of the
+# process (streams and device pointers are shared with torch), so it has to be
+# loaded before libgenie_hip.so resolves the same SONAME.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GENIE_HIP_LIB', os.path.join(_HERE, 'lib', 'libgenie_hip.so'))
 

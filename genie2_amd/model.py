@@ -1,0 +1,115 @@
+"""`Denoiser`: drop-in for genie.model.model.Denoiser (genie/model/model.py:10-192).
+
+Same constructor signature, same `state_dict()` keys and shapes (so reference
+checkpoints load unchanged), same call `model(ts, timesteps, features)['z']`
+-- but `forward` is one call into libgenie_hip.so.  It is inference only
+(no autograd through the HIP kernels) and has no CPU path: calling it on a CPU
+device raises.
+"""
+import torch
+from torch import nn
+
+from . import pack
+from .affine import T
+from .capi import GenieError
+from .engine import GenieEngine
+
+
+class _Node(nn.Module):
+    """Anonymous container so that parameters get the reference's dotted names."""
+
+
+class Denoiser(nn.Module):
+    def __init__(self, c_s, c_p, n_timestep, rescale, c_pos_emb, c_chain_emb, c_timestep_emb, max_n_res, max_n_chain,
+                 relpos_k, template_dist_min, template_dist_step, template_dist_n_bin, n_pair_transform_layer,
+                 include_mul_update, include_tri_att, c_hidden_mul, c_hidden_tri_att, n_head_tri, tri_dropout,
+                 pair_transition_n, n_structure_layer, n_structure_block, c_hidden_ipa, n_head_ipa, n_qk_point, n_v_point,
+                 ipa_dropout, n_structure_transition_layer, structure_transition_dropout):
+        super().__init__()
+        if include_tri_att:
+            raise NotImplementedError('triangular attention is disabled in every Genie 2 config and is not built here')
+        if not include_mul_update and n_pair_transform_layer > 0:
+            raise NotImplementedError('pair transform layers without triangular multiplication are not supported')
+        if n_structure_transition_layer != 1:
+            raise NotImplementedError('n_structure_transition_layer must be 1')
+        self.rescale = rescale
+        self.dims = dict(
+            c_s=c_s, c_p=c_p, c_pos_emb=c_pos_emb, c_chain_emb=c_chain_emb, c_timestep_emb=c_timestep_emb,
+            relpos_k=relpos_k, template_dist_n_bin=template_dist_n_bin, template_dist_min=float(template_dist_min),
+            template_dist_step=float(template_dist_step), n_pair_transform_layer=n_pair_transform_layer,
+            c_hidden_mul=c_hidden_mul, pair_transition_n=pair_transition_n, n_structure_layer=n_structure_layer,
+            n_structure_block=n_structure_block, c_hidden_ipa=c_hidden_ipa, n_head_ipa=n_head_ipa, n_qk_point=n_qk_point,
+            n_v_point=n_v_point, rescale=float(rescale), n_timestep=n_timestep, max_n_res=max_n_res, max_n_chain=max_n_chain)
+        init = pack.random_state_dict(self.dims, seed=0)
+        for key, _ in pack.weight_layout(self.dims):
+            *path, leaf = key.split('.')
+            node = self
+            for name in path:
+                if not hasattr(node, name):
+                    node.add_module(name, _Node())
+                node = getattr(node, name)
+            node.register_parameter(leaf, nn.Parameter(init[key], requires_grad=False))
+        self._engine = None
+        self._bound = None
+
+    # -- engine lifetime: any change of parameters or device drops the packed copy
+    def _apply(self, fn, *a, **k):
+        self._drop_engine()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._drop_engine()
+        return super().load_state_dict(*a, **k)
+
+    def _drop_engine(self):
+        if getattr(self, '_engine', None) is not None:
+            self._engine.close()
+        self._engine = None
+        self._bound = None
+
+    def engine(self):
+        dev = next(self.parameters()).device
+        if dev.type != 'cuda':
+            raise GenieError('Denoiser.forward runs only on a GPU (libgenie_hip); move the model with .to("cuda:N")')
+        if self._engine is None:
+            self._engine = GenieEngine(self.dims, {k: v for k, v in self.state_dict().items()}, dev)
+        return self._engine
+
+    def bind(self, features):
+        """Bind a batch of features (done implicitly by forward; the step-invariant
+        pair terms are recomputed only when the feature tensors change)."""
+        eng = self.engine()
+        sig = tuple((k, features[k].data_ptr(), tuple(features[k].shape), features[k]._version)
+                    for k in ('residue_mask', 'residue_index', 'chain_index', 'aatype', 'atom_positions',
+                              'fixed_sequence_mask', 'fixed_structure_mask', 'interface_mask'))
+        if sig != self._bound:
+            eng.bind_features(features)
+            self._bound = sig
+        return eng
+
+    def forward(self, ts, timesteps, features, outputs=('z',), quat_codes=None):
+        """Returns a dict with 'z' [B,N,3] (what the samplers consume) and, when
+        named in `outputs`, 's', 'p', 'states' ([2,B,N,c_s]: first and last of
+        the reference's list) and 'ts' (updated frames)."""
+        eng = self.bind(features)
+        taps = set()
+        if 's' in outputs or 'states' in outputs:
+            taps.add('s')
+        if 'states' in outputs:
+            taps.add('s_final')
+        if 'p' in outputs:
+            taps.add('p')
+        if 'ts' in outputs:
+            taps.update(('rots_out', 'trans_out'))
+        with torch.no_grad():
+            raw = eng.denoise(ts.trans, ts.rots, timesteps, quat_codes, tuple(sorted(taps)))
+        out = {'z': raw['z']}
+        if 's' in outputs:
+            out['s'] = raw['s']
+        if 'p' in outputs:
+            out['p'] = raw['p']
+        if 'states' in outputs:
+            out['states'] = torch.stack([raw['s'], raw['s_final']])
+        if 'ts' in outputs:
+            out['ts'] = T(raw['rots_out'], raw['trans_out'])
+        return out

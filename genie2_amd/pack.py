@@ -132,3 +132,31 @@ def schedule_block(sched):
     """[4][T+1] block for genie_set_tables."""
     return torch.stack([sched['alphas'], sched['sqrt_alphas'], sched['sqrt_one_minus_alphas_cumprod'],
                         sched['sqrt_betas']]).float().contiguous()
+
+
+def random_state_dict(dims, seed=0):
+    """Random-init weights of the Denoiser architecture for benchmarking
+    (trained checkpoints are not available offline).  Unlike the reference's
+    default init (primitives.py:76-83,157-158: 'final' layers are zero) every
+    matrix is non-zero so that no kernel runs on trivial operands."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for key, shape in weight_layout(dims):
+        if key.endswith('head_weights'):
+            t = 0.5413 + 0.3 * torch.randn(shape, generator=g)
+        elif 'layer_norm' in key:
+            t = (1.0 if key.endswith('weight') else 0.0) + 0.1 * torch.randn(shape, generator=g)
+        elif key.endswith('bias'):
+            t = 0.1 * torch.randn(shape, generator=g) + (1.0 if ('_g.bias' in key or 'linear_g.bias' in key) else 0.0)
+        else:
+            t = torch.randn(shape, generator=g) * ((0.1 if 'bb_update' in key else 1.0) / math.sqrt(shape[1]))
+        sd[key] = t.float().contiguous()
+    return sd
+
+
+BASE_DIMS = dict(
+    c_s=384, c_p=128, rescale=1.0, c_pos_emb=256, c_chain_emb=64, c_timestep_emb=512,
+    relpos_k=32, template_dist_min=2.0, template_dist_step=0.5, template_dist_n_bin=37,
+    n_pair_transform_layer=5, c_hidden_mul=128, pair_transition_n=4,
+    n_structure_layer=8, n_structure_block=1, c_hidden_ipa=16, n_head_ipa=12, n_qk_point=4, n_v_point=8,
+    n_timestep=1000, max_n_res=256, max_n_chain=1)

@@ -28,10 +28,15 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 REF = os.environ.get('GENIE_REFERENCE', '/root/reference')
-sys.path.insert(0, REF)
-sys.path.insert(0, ROOT)
+# The repo root also holds a `genie` compatibility package; keep it OFF sys.path here
+# so that `genie.*` below is the real reference.
+import importlib.util  # noqa: E402
 
-from oracle import genie_oracle as O  # noqa: E402
+_spec = importlib.util.spec_from_file_location('genie_oracle', os.path.join(HERE, 'genie_oracle.py'))
+O = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(O)
+sys.path[:] = [p for p in sys.path if os.path.abspath(p or '.') != ROOT]
+sys.path.insert(0, REF)
 
 from genie.config import Config  # noqa: E402  (reference)
 from genie.model.model import Denoiser  # noqa: E402
@@ -342,6 +347,7 @@ def main():
         h.update(sd[k].numpy().tobytes())
     save('weights_recipe', sha256=np.frombuffer(h.digest(), dtype=np.uint8),
          n_params=sum(v.numel() for v in sd.values()),
+         keys=np.array(list(ref_sd.keys())), shapes=np.array([str(tuple(v.shape)) for v in ref_sd.values()]),
          probe=sd['structure_net.net.7.ipa.linear_out.weight'][:4, :8])
     print('schedule'); gen_schedule()
     print('encoding'); gen_encoding()

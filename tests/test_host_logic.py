@@ -1,0 +1,185 @@
+"""Host logic and the C-ABI surface.  CPU only: no compute call reaches the GPU."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+
+def test_library_exports_every_declared_symbol():
+    from genie2_amd import build, capi
+    build.build()
+    lib = capi.load_library()
+    header = open(os.path.join(ROOT, 'include', 'genie_hip.h')).read()
+    declared = set(re.findall(r'\b(genie_[a-z_]+)\s*\(', header))
+    assert declared, 'no declarations parsed'
+    assert declared == set(capi.SYMBOLS), (declared ^ set(capi.SYMBOLS))
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_create_fails_loudly_without_gpu_or_bad_dims():
+    import ctypes as C
+    from genie2_amd import capi, pack
+    lib = capi.load_library()
+    bad = dict(pack.BASE_DIMS, c_p=64)
+    h = C.c_void_p()
+    rc = lib.genie_create(C.byref(capi.GenieDims(**bad)), 0, C.byref(h))
+    assert rc == -1 and b'c_p' in lib.genie_last_error(None)
+    if not torch.cuda.is_available():
+        from genie2_amd.engine import GenieEngine
+        with pytest.raises(capi.GenieError):
+            GenieEngine(pack.BASE_DIMS, pack.random_state_dict(pack.BASE_DIMS), 'cuda:0')
+        with pytest.raises(capi.GenieError):
+            GenieEngine(pack.BASE_DIMS, {}, 'cpu')
+
+
+def test_weight_layout_matches_reference_state_dict():
+    from genie2_amd import pack
+    g = load_golden('weights_recipe')
+    lay = pack.weight_layout(pack.BASE_DIMS)
+    assert [k for k, _ in lay] == list(g['keys'])
+    assert [str(tuple(s)) for _, s in lay] == list(g['shapes'])
+    assert sum(int(np.prod(s)) for _, s in lay) == int(g['n_params']) == 15732080
+
+
+def test_weight_count_matches_c_library():
+    import ctypes as C
+    from genie2_amd import capi, pack
+    from oracle import genie_oracle as O
+    lib = capi.load_library()
+    for dims in (pack.BASE_DIMS, O.small_dims(), O.small_dims(c_s=256, n_head_ipa=8, n_v_point=4, pair_transition_n=2)):
+        n = sum(int(np.prod(s)) for _, s in pack.weight_layout(dims))
+        assert n == lib.genie_weight_count(C.byref(capi.GenieDims(**{k: dims[k] for k in pack.DIM_KEYS})))
+
+
+def test_flatten_state_dict_checks_keys_and_shapes():
+    from genie2_amd import pack
+    from oracle import genie_oracle as O
+    d = O.small_dims()
+    sd = pack.random_state_dict(d)
+    blob = pack.flatten_state_dict({'model.' + k: v for k, v in sd.items()}, d)      # checkpoint prefix accepted
+    assert blob.numel() == sum(v.numel() for v in sd.values())
+    bad = dict(sd)
+    bad.pop('single_feature_net.linear.weight')
+    with pytest.raises(KeyError):
+        pack.flatten_state_dict(bad, d)
+    bad = dict(sd)
+    bad['single_feature_net.linear.weight'] = torch.zeros(3, 3)
+    with pytest.raises(ValueError):
+        pack.flatten_state_dict(bad, d)
+
+
+def test_tables_and_schedule_match_reference():
+    from genie2_amd import pack
+    g = load_golden('encoding')
+    for nm, (vmax, N, D) in dict(pos=(256, 256, 256), chain=(4, 1, 64), t1000=(1001, 1000, 512)).items():
+        tab = pack.sinusoidal_table(vmax, N, D)
+        assert torch.equal(tab[torch.from_numpy(g[nm + '_rows'])], torch.from_numpy(g[nm + '_vals']))
+    s = load_golden('schedule')
+    assert torch.equal(pack.cosine_betas(1000), torch.from_numpy(s['betas_1000']))
+    blk = pack.schedule_block(pack.schedule_tensors(100))
+    assert blk.shape == (4, 101) and blk[0, 0] == 1 and blk[3, 0] == 0
+
+
+def test_feature_dicts_and_pdb_writer():
+    from genie2_amd import features as F
+    g = load_golden('pdb_writer')
+    f = F.create_empty_np_features([7])
+    f['atom_positions'] = g['atom_positions']
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, 'x.pdb')
+        F.save_np_features_to_pdb(f, p)
+        assert open(p, 'rb').read() == g['pdb_bytes'].tobytes()      # byte-exact with the reference's writer
+    b = F.batchify_np_features([F.create_empty_np_features([5]), F.create_empty_np_features([3, 4])])
+    assert b['aatype'].shape == (2, 7, 20) and b['fixed_structure_mask'].shape == (2, 7, 7)
+    assert b['residue_mask'].tolist() == [[1, 1, 1, 1, 1, 0, 0], [1] * 7]
+    assert b['chain_index'][1].tolist() == [0, 0, 0, 1, 1, 1, 1] and b['residue_index'][1].tolist() == [0, 1, 2, 0, 1, 2, 3]
+    tt = F.convert_np_features_to_tensor(b, 'cpu')
+    assert tt['residue_mask'].dtype == torch.int32 and tt['fixed_structure_mask'].dtype == torch.bool
+    back = F.debatchify_np_features(F.convert_tensor_features_to_numpy(tt))
+    assert back[0]['atom_positions'].shape == (5, 3) and back[1]['num_residues_per_chain'].tolist() == [3, 4]
+
+
+def test_config_parser_defaults_and_file():
+    from genie2_amd.config import Config
+    c = Config()
+    assert c.model['c_s'] == 384 and c.model['n_pair_transform_layer'] == 5 and c.diffusion['n_timestep'] == 1000
+    assert c.io['max_n_res'] == 256 and c.model['include_tri_att'] is False
+    with tempfile.NamedTemporaryFile('w', suffix='.cfg', delete=False) as fh:
+        fh.write('name base\n\nnumPairTransformLayers 3\nincludeTriangularAttention False\nrescale 2.5\nbad line here\n')
+    c = Config(fh.name)
+    os.unlink(fh.name)
+    assert c.io['name'] == 'base' and c.model['n_pair_transform_layer'] == 3 and c.model['rescale'] == 2.5
+
+
+def test_api_surface_mirrors_reference_paths():
+    from genie.sampler.base import BaseSampler
+    from genie.sampler.unconditional import UnconditionalSampler
+    from genie.model.model import Denoiser
+    from genie.config import Config
+    from genie.utils.affine_utils import T
+    from genie.diffusion.schedule import get_betas
+    from genie.utils.multiprocessor import MultiProcessor  # noqa: F401
+    assert issubclass(UnconditionalSampler, BaseSampler)
+    assert get_betas(10, 'cosine').shape == (11,)
+    c = Config()
+    m = Denoiser(**c.model, n_timestep=1000, max_n_res=256, max_n_chain=1)
+    g = load_golden('weights_recipe')
+    assert list(m.state_dict().keys()) == list(g['keys'])
+    t = T(None, torch.zeros(2, 5, 3))
+    assert t.rots.shape == (2, 5, 3, 3) and t[0].trans.shape == (5, 3)
+    from genie2_amd.capi import GenieError
+    with pytest.raises(GenieError):            # the product path has no CPU fallback
+        m(t, torch.ones(2, dtype=torch.int32), {})
+
+
+def test_cli_flags_and_task_split():
+    from genie2_amd.sample_unconditional import UnconditionalRunner, build_parser
+    from genie2_amd.multiprocessor import split_tasks
+    a = build_parser().parse_args(['--name', 'base', '--epoch', '40', '--scale', '0.6', '--outdir', 'o'])
+    assert (a.num_samples, a.batch_size, a.min_length, a.max_length, a.length_step, a.num_devices) == (5, 4, 50, 256, 1, 1)
+    tasks = UnconditionalRunner().create_tasks(dict(min_length=50, max_length=256, length_step=16))
+    assert [t['length'] for t in tasks] == list(range(256, 49, -16)) and len(tasks) == 13      # 50 itself is never visited
+    bins = split_tasks(tasks, 8)
+    assert [len(b) for b in bins] == [2, 2, 2, 2, 2, 2, 1, 0]                                    # reference's imbalance quirk
+    assert sum(bins, []) == tasks
+
+
+_DIST_WORKER = r'''
+import os, sys, torch, torch.distributed as td
+sys.path.insert(0, sys.argv[1])
+from genie2_amd import distributed as D
+td.init_process_group('gloo', rank=int(os.environ['RANK']), world_size=2)
+r = td.get_rank()
+tasks = list(range(5))
+mine = D.rank_tasks(tasks)
+assert mine == ([0, 1, 2] if r == 0 else [3, 4]), mine
+t = D.max_over_ranks(1.0 + r)
+assert t == 2.0
+x = torch.full((2, 4, 3), float(r))
+g = D.gather_coordinates(x)
+assert g.shape == (4, 4, 3) and g[:2].eq(0).all() and g[2:].eq(1).all()
+td.destroy_process_group()
+print('ok', r)
+'''
+
+
+def test_two_rank_gloo_path():
+    """world_size 2 on CPU: task sharding, max-over-ranks timing, result gather."""
+    with tempfile.NamedTemporaryFile('w', suffix='.py', delete=False) as fh:
+        fh.write(_DIST_WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29533')
+        procs.append(subprocess.Popen([sys.executable, fh.name, ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = [p.communicate(timeout=120) for p in procs]
+    os.unlink(fh.name)
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e.decode()[-2000:]

@@ -1,0 +1,85 @@
+"""The oracle (oracle/genie_oracle.py) against the fixtures generated from the
+real reference (oracle/make_goldens.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import CALL_CASES, golden_features, load_golden
+from oracle import genie_oracle as O
+
+
+def t(x):
+    return torch.from_numpy(np.asarray(x))
+
+
+def test_schedule_matches_reference():
+    g = load_golden('schedule')
+    for T in (100, 1000):
+        b = O.cosine_beta_schedule(T)
+        assert b.shape == (T + 1,) and b[0] == 0
+        assert torch.equal(b, t(g[f'betas_{T}']))
+    s = O.setup_schedule(1000)
+    assert abs(float(s['betas'][1]) - 2.5e-6) < 1e-6 and abs(float(s['betas'][1000]) - 0.75003) < 1e-4
+
+
+def test_encoding_matches_reference():
+    g = load_golden('encoding')
+    for nm, (vmax, N, D) in dict(pos=(256, 256, 256), chain=(4, 1, 64), t1000=(1001, 1000, 512), t100=(101, 100, 512)).items():
+        e = O.sinusoidal_encoding(torch.arange(vmax, dtype=torch.int32), N, D)
+        assert torch.equal(e[t(g[nm + '_rows'])], t(g[nm + '_vals']))
+        assert abs(float(e.double().sum()) - float(g[nm + '_sum'])) < 1e-6
+
+
+def test_frenet_matches_reference():
+    g = load_golden('geometry')
+    r = O.compute_frenet_frames(t(g['frenet_coords']), t(g['frenet_chains']), t(g['frenet_mask']))
+    assert torch.equal(r, t(g['frenet_rots']))
+    # improper frames (det = -1) inside a chain, identity on padding
+    assert torch.allclose(torch.linalg.det(r[0]), -torch.ones(24), atol=1e-4)
+    assert torch.equal(r[3, 5:], torch.eye(3).expand(19, 3, 3))
+
+
+def test_quaternions_match_reference():
+    g = load_golden('geometry')
+    assert torch.allclose(O.quat_to_rot(t(g['q2r_q'])), t(g['q2r_r']), atol=1e-6)
+    q_ref = t(g['r2q_q'])
+    q = O.apply_sign_codes(O.rot_to_quat_closed(t(g['r2q_r'])), t(g['r2q_codes']))
+    assert (q - q_ref).abs().max() < 2e-4          # fp32 eigh itself is only ~4e-5 accurate
+    assert torch.equal(O.quat_sign_codes(q_ref), t(g['r2q_codes']))
+
+
+@pytest.mark.parametrize('case', CALL_CASES)
+def test_denoiser_call_matches_reference(case, base_weights):
+    g = load_golden('call_' + case)
+    f = golden_features(g)
+    B, N = f['residue_mask'].shape
+    ts = torch.full((B,), int(g['timestep']), dtype=torch.int32)
+    taps = {}
+    out = O.denoiser_forward(base_weights, dict(O.BASE_DIMS), t(g['rots']), t(g['trans']), ts, f, 'closed',
+                             t(g['quat_codes']), taps)
+    m = f['residue_mask'].unsqueeze(-1).float()
+    zref = t(g['z'])
+    assert ((out['z'] - zref) * m).abs().max() <= 1e-4 * max(1.0, float(zref.abs().max()))
+    assert (out['s'] - t(g['s'])).abs().max() < 1e-5
+    idx = t(g['p_idx']).long()
+    for key, val in (('p_final_samples', out['p']), ('p_init_samples', taps['p_init']),
+                     ('p_layer0_samples', taps['p_after_layer0'])):
+        got = val[idx[:, 0], idx[:, 1], idx[:, 2]]
+        assert (got - t(g[key])).abs().max() <= 2e-4 * max(1.0, float(np.abs(g[key]).max())), key
+    assert ((out['s_final'] - t(g['states'])[1]) * m).abs().max() < 2e-3
+    # eigh mode reproduces the reference's own call up to eigh's sign choice on this machine
+    out_e = O.denoiser_forward(base_weights, dict(O.BASE_DIMS), t(g['rots']), t(g['trans']), ts, f, 'eigh')
+    assert torch.isfinite(out_e['z']).all()
+
+
+def test_trajectory_matches_reference(base_weights):
+    """Config 1: N=50, T=100, B=1, scale 0.6 with the reference's own noise and eigh signs."""
+    g = load_golden('trajectory_n50_t100')
+    dims = dict(O.BASE_DIMS, n_timestep=100)
+    f = O.empty_features([50])
+    final, _, rec = O.sample_loop(base_weights, dims, f, t(g['noise']), float(g['scale']), 'closed', t(g['quat_codes']),
+                                  record_every=10)
+    ref = t(g['final'])
+    rms = float(ref.pow(2).mean().sqrt())
+    assert (final - ref).abs().max() <= 1e-4 * rms
+    assert (torch.stack(rec) - t(g['every10'])).abs().max() <= 1e-4 * rms
