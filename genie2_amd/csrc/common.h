@@ -51,6 +51,49 @@ __device__ __forceinline__ float4 wfrag(const float* __restrict__ wp, int KB, in
     return *reinterpret_cast<const float4*>(wp + ((size_t)(nb * KB + kb) * 64 + lane) * 4);
 }
 
+// ---- software-pipelined weight fragments -------------------------------------------------
+// hipcc places every load right before its first use (one L2 round trip exposed per k-block) and
+// undoes source-level register rotation, so the prefetch is written with loads it cannot see:
+//   wf_issue()  : global_load_dwordx4 the compiler does not count (asm), destination "=v";
+//   wf_wait<N>(): s_waitcnt vmcnt(N) tied ("+v") to the registers it releases + scheduling fence,
+//                 so no consumer can be placed above it.
+// Counting rule (vector-memory ops retire in order): N = number of THIS wave's asm loads issued
+// after the ones being released.  Compiler-issued loads/stores in between can only make the wait
+// stricter, never weaker.  Every asm load must be retired (wf_wait<0>) before its destination
+// registers die, otherwise a late write-back would land in a reused register.
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ const float* wfrag_ptr(const float* __restrict__ wp, int KB, int nb, int kb, int lane) {
+    return wp + ((size_t)(nb * KB + kb) * 64 + lane) * 4;
+}
+__device__ __forceinline__ void wf_issue(v4f& d, const float* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wf_wait(v4f& a) {
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "i"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int N>
+__device__ __forceinline__ void wf_wait(v4f& a, v4f& b) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ f32x16 mfma_8k(const v4f a, const float4 b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, c, 0, 0, 0);
+    return c;
+}
+__device__ __forceinline__ f32x16 mfma_8k(const float4 a, const v4f b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, c, 0, 0, 0);
+    return c;
+}
+
 // K-contiguous LDS tile fragment: rows r0..r0+31, k-block kb
 __device__ __forceinline__ float4 lfrag(const float* lds, int ld, int r0, int kb, int lane) {
     return *reinterpret_cast<const float4*>(lds + (r0 + (lane & 31)) * ld + kb * 8 + 4 * (lane >> 5));
@@ -134,6 +177,8 @@ struct StructLayerW {
 struct genie_ctx {
     genie_dims_t d;
     int device;
+    int pair_impl;                // bit set = LDS-tile version, clear = wave-independent version; bit 0 trimul_proj,
+                                  // 1 trimul_out, 2 pair_transition (GENIE_PAIR_TILE_MASK, default 2)
     char err[512];
 
     // weights

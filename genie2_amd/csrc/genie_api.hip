@@ -92,6 +92,7 @@ int genie_create(const genie_dims_t* dims, int device, genie_handle_t* out) {
     memset(h, 0, sizeof(*h));
     h->d = *dims;
     h->device = device;
+    { const char* e = getenv("GENIE_PAIR_TILE_MASK"); h->pair_impl = e ? atoi(e) : 2; }
     if (hipSetDevice(device) != hipSuccess) { delete h; snprintf(g_create_err, sizeof g_create_err, "hipSetDevice failed"); return GENIE_E_HIP; }
     h->pair = new PairLayerW[dims->n_pair_transform_layer > 0 ? dims->n_pair_transform_layer : 1]();
     h->st = new StructLayerW[dims->n_structure_layer]();

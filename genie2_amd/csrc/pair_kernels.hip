@@ -5,17 +5,32 @@
 
 #define LDZ 132   // 128-channel tile row stride (floats): conflict-free ds_read_b128
 #define LDX 68    // 64-wide M-contiguous tile row stride
+#ifndef PROJ_PD
+#define PROJ_PD 4
+#endif
+#ifndef PROJ_OCC
+#define PROJ_OCC 3
+#endif
 
 // Load 64 pair rows x 128 channels (row t at src + t*row_stride) into tile[64][LDZ].
 __device__ __forceinline__ void load_tile64(float* tile, const float* __restrict__ src, size_t row_stride,
                                             int nvalid, int tid) {
+    // All eight row loads are issued before the first LDS write (unconditional loads from a
+    // clamped row, zeroed afterwards): one HBM round trip per tile instead of eight.
     const int c4 = tid & 31;
-    int r = tid >> 5;
+    const int r0 = tid >> 5;
+    float4 v[8];
+    const int last = max(nvalid - 1, 0);
 #pragma unroll
-    for (int u = 0; u < 8; ++u, r += 8) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < nvalid) v = *reinterpret_cast<const float4*>(src + (size_t)r * row_stride + c4 * 4);
-        *reinterpret_cast<float4*>(tile + r * LDZ + c4 * 4) = v;
+    for (int u = 0; u < 8; ++u) {
+        const int r = min(r0 + 8 * u, last);
+        v[u] = *reinterpret_cast<const float4*>(src + (size_t)r * row_stride + c4 * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int r = r0 + 8 * u;
+        if (r >= nvalid) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(tile + r * LDZ + c4 * 4) = v[u];
     }
 }
 
@@ -31,7 +46,7 @@ __device__ __forceinline__ void load_tile64(float* tile, const float* __restrict
 // which makes every store a 128-B run.
 // ---------------------------------------------------------------------------
 template <bool OUTGOING>
-__global__ __launch_bounds__(256) void k_trimul_proj(const float* __restrict__ z, const float* __restrict__ rmask,
+__global__ __launch_bounds__(256, PROJ_OCC) void k_trimul_proj(const float* __restrict__ z, const float* __restrict__ rmask,
                                                      const float* __restrict__ wp, const float* __restrict__ bias,
                                                      const float* __restrict__ lng, const float* __restrict__ lnb,
                                                      float* __restrict__ acm, float* __restrict__ bcm, int N, int NP) {
@@ -54,20 +69,43 @@ __global__ __launch_bounds__(256) void k_trimul_proj(const float* __restrict__ z
     ln_rows_128(zt, LDZ, lng, lnb, tid);
     __syncthreads();
 
+    // Weight fragments run PROJ_PD k-blocks (PROJ_PD x 1024 MFMA cycles) ahead of the MFMAs in a
+    // rotating register ring (common.h, "software-pipelined weight fragments"); the ring is kept
+    // full across the two channel-group passes, so only the very first fill is exposed.
+    v4f wq[PROJ_PD][2];
+#pragma unroll
+    for (int s = 0; s < PROJ_PD; ++s) {
+        wf_issue(wq[s][0], wfrag_ptr(wp, 16, wave, s, lane));
+        wf_issue(wq[s][1], wfrag_ptr(wp, 16, 8 + wave, s, lane));
+    }
     for (int it = 0; it < 2; ++it) {
         const int cg = wave + 4 * it;          // 0..3 -> a channels, 4..7 -> b channels
         const int nb_p = cg, nb_g = 8 + cg;
         f32x16 ap0 = zero16(), ap1 = zero16(), ag0 = zero16(), ag1 = zero16();
-#pragma unroll 4
-        for (int kb = 0; kb < 16; ++kb) {
-            const float4 wpf = wfrag(wp, 16, nb_p, kb, lane);
-            const float4 wgf = wfrag(wp, 16, nb_g, kb, lane);
-            const float4 z0 = lfrag(zt, LDZ, 0, kb, lane);
-            const float4 z1 = lfrag(zt, LDZ, 32, kb, lane);
-            ap0 = mfma_8k(wpf, z0, ap0);
-            ap1 = mfma_8k(wpf, z1, ap1);
-            ag0 = mfma_8k(wgf, z0, ag0);
-            ag1 = mfma_8k(wgf, z1, ag1);
+#pragma unroll 1
+        for (int kb0 = 0; kb0 < 16; kb0 += PROJ_PD) {
+#pragma unroll
+            for (int s = 0; s < PROJ_PD; ++s) {
+                const int kb = kb0 + s;
+                const float4 z0 = lfrag(zt, LDZ, 0, kb, lane);
+                const float4 z1 = lfrag(zt, LDZ, 32, kb, lane);
+                wf_wait<2 * (PROJ_PD - 1)>(wq[s][0], wq[s][1]);
+                ap0 = mfma_8k(wq[s][0], z0, ap0);
+                ap1 = mfma_8k(wq[s][0], z1, ap1);
+                ag0 = mfma_8k(wq[s][1], z0, ag0);
+                ag1 = mfma_8k(wq[s][1], z1, ag1);
+                __builtin_amdgcn_sched_barrier(0);
+                // refill slot s: k-block kb + PD of this pass, or the head of the next pass
+                // (past the very end: a harmless re-load that keeps the in-flight count uniform)
+                int kn = kb + PROJ_PD, np = nb_p, ng = nb_g;
+                if (kn >= 16) { if (it == 0) { kn -= 16; np += 4; ng += 4; } else { kn = 15; } }
+                wf_issue(wq[s][0], wfrag_ptr(wp, 16, np, kn, lane));
+                wf_issue(wq[s][1], wfrag_ptr(wp, 16, ng, kn, lane));
+            }
+        }
+        if (it == 1) {    // retire the ring before its registers are reused
+#pragma unroll
+            for (int s = 0; s < PROJ_PD; ++s) wf_wait<0>(wq[s][0], wq[s][1]);
         }
         float* dst = (cg < 4) ? acm : bcm;
         const int chbase = (cg & 3) * 32;
@@ -110,10 +148,10 @@ __global__ __launch_bounds__(256) void k_trimul_contract(const float* __restrict
 #pragma unroll
         for (int u = 0; u < TM / 32; ++u) {
             const int r = lr + 32 * u;
-            ra[u] = (i0 + r < NP) ? *reinterpret_cast<const float4*>(A + (size_t)(i0 + r) * NP + kc * 32 + c4 * 4)
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[u] = (j0 + r < NP) ? *reinterpret_cast<const float4*>(Bm + (size_t)(j0 + r) * NP + kc * 32 + c4 * 4)
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 ta = *reinterpret_cast<const float4*>(A + (size_t)min(i0 + r, NP - 1) * NP + kc * 32 + c4 * 4);
+            const float4 tb = *reinterpret_cast<const float4*>(Bm + (size_t)min(j0 + r, NP - 1) * NP + kc * 32 + c4 * 4);
+            ra[u] = (i0 + r < NP) ? ta : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[u] = (j0 + r < NP) ? tb : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto swrite = [&](int buf) {
@@ -177,7 +215,7 @@ __global__ __launch_bounds__(256) void k_trimul_contract(const float* __restrict
 // never goes through HBM.  x arrives channel-major and is consumed as an
 // M-contiguous LDS tile [c][j].
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_trimul_out(float* __restrict__ z, const float* __restrict__ xcm,
+__global__ __launch_bounds__(256, 4) void k_trimul_out(float* __restrict__ z, const float* __restrict__ xcm,
                                                     const float* __restrict__ wg, const float* __restrict__ bg,
                                                     const float* __restrict__ wz, const float* __restrict__ bz,
                                                     const float* __restrict__ ln_in_g, const float* __restrict__ ln_in_b,
@@ -218,12 +256,17 @@ __global__ __launch_bounds__(256) void k_trimul_out(float* __restrict__ z, const
     {
         const int f4 = tid & 15;
         const int j = t0 + 4 * f4;
+        float4 xv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int c = (tid >> 4) + 16 * u;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < NP) v = *reinterpret_cast<const float4*>(xcm + (((size_t)b * 128 + c) * NP + i) * NP + j);
-            *reinterpret_cast<float4*>(buf + c * LDX + 4 * f4) = v;
+            xv[u] = *reinterpret_cast<const float4*>(xcm + (((size_t)b * 128 + c) * NP + i) * NP + min(j, NP - 4));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = (tid >> 4) + 16 * u;
+            if (j >= NP) xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(buf + c * LDX + 4 * f4) = xv[u];
         }
     }
     __syncthreads();
@@ -356,7 +399,11 @@ __global__ __launch_bounds__(256) void k_ipa_bias(const float* __restrict__ z, c
     const int nvalid = min(128, N - t0);
     const float* src = z + (((size_t)b * N + i) * N + t0) * 128;
     load_tile64(sm, src, 128, nvalid, tid);
-    load_tile64(sm + 64 * LDZ, src + (size_t)64 * 128, 128, nvalid - 64, tid);
+    if (nvalid > 64) {
+        load_tile64(sm + 64 * LDZ, src + (size_t)64 * 128, 128, nvalid - 64, tid);
+    } else {
+        for (int u = tid; u < 64 * LDZ / 4; u += 256) reinterpret_cast<float4*>(sm + 64 * LDZ)[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     __syncthreads();
     const int nbo = (LH + 31) >> 5;
     const int t = wave * 32 + (lane & 31);
@@ -601,12 +648,18 @@ void launch_pair_init(genie_ctx* h, hipStream_t st, const float* trans, const fl
                        h->d.template_dist_n_bin);
 }
 
+void launch_trimul_proj_wi(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgoing);
+void launch_trimul_out_wi(genie_ctx* h, hipStream_t st, const TriMulW& w);
+void launch_pair_transition_wi(genie_ctx* h, hipStream_t st, const PairLayerW& w);
+
 void launch_trimul(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgoing) {
     const int N = h->N, NP = h->NP, ntile = (N + 63) / 64;
     {
         ProfScope ps(h, st, KC_TRIMUL_PROJ);
         dim3 grid(h->B * N * ntile);
-        if (outgoing)
+        if (!(h->pair_impl & 1))
+            launch_trimul_proj_wi(h, st, w, outgoing);
+        else if (outgoing)
             hipLaunchKernelGGL(k_trimul_proj<true>, grid, dim3(256), 0, st, h->p, h->rmaskf, w.proj_w, w.proj_b, w.ln_in_g,
                                w.ln_in_b, h->acm, h->bcm, N, NP);
         else
@@ -628,13 +681,17 @@ void launch_trimul(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgoing
     }
     {
         ProfScope ps(h, st, KC_TRIMUL_OUT);
-        hipLaunchKernelGGL(k_trimul_out, dim3(h->B * N * ntile), dim3(256), 0, st, h->p, h->xcm, w.g_w, w.g_b, w.z_w, w.z_b,
+        if (!(h->pair_impl & 2))
+            launch_trimul_out_wi(h, st, w);
+        else
+            hipLaunchKernelGGL(k_trimul_out, dim3(h->B * N * ntile), dim3(256), 0, st, h->p, h->xcm, w.g_w, w.g_b, w.z_w, w.z_b,
                            w.ln_in_g, w.ln_in_b, w.ln_out_g, w.ln_out_b, N, NP);
     }
 }
 
 void launch_pair_transition(genie_ctx* h, hipStream_t st, const PairLayerW& w) {
     ProfScope ps(h, st, KC_PAIR_TRANSITION);
+    if (!(h->pair_impl & 4)) { launch_pair_transition_wi(h, st, w); return; }
     const long long M = (long long)h->B * h->N * h->N;
     const size_t lds = (2 * 64 * LDZ + 64) * sizeof(float);
     hipLaunchKernelGGL(k_pair_transition, dim3((unsigned)((M + 63) / 64)), dim3(256), lds, st, h->p, h->rmaskf, w.pt_ln_g,

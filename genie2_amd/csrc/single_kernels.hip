@@ -60,7 +60,9 @@ __global__ __launch_bounds__(256) void k_gemm_rows(const float* __restrict__ A, 
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int r = r0 + lr + 16 * u, k = kc * 64 + c4 * 4;
-            ra[u] = (r < M && k < K) ? *reinterpret_cast<const float4*>(A + (size_t)r * lda + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            // unconditional load from a clamped address, zeroed afterwards: keeps both loads in flight
+            const float4 t = *reinterpret_cast<const float4*>(A + (size_t)min(r, M - 1) * lda + min(k, K - 4));
+            ra[u] = (r < M && k < K) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto swrite = [&](int buf) {
@@ -318,6 +320,173 @@ __global__ __launch_bounds__(256) void k_ipa_attn(const float* __restrict__ proj
 }
 
 // ---------------------------------------------------------------------------
+// IPA attention core, compile-time shapes (the Genie 2 config H=12, C=16, Pq=4, Pv=8, c_p=128).
+// Same maths as k_ipa_attn; every inner loop has a constant trip count so hipcc batches the
+// (L2-resident) operand loads instead of paying one round trip per scalar, the j loops are
+// unrolled x8 / x4, the o_pair partials of the two half-waves are merged with a lane-32 shuffle
+// before LDS (24 KB instead of 48 KB -> 4 work-groups per CU).
+// Dynamic LDS: att[H][NP8] | red[4][H][128] (aliases the q / q_pts scratch) | opt[H*Pv*3].
+// ---------------------------------------------------------------------------
+template <int H, int C, int PQ, int PV>
+__global__ __launch_bounds__(256) void k_ipa_attn_t(const float* __restrict__ proj, int ldp, const float* __restrict__ kT,
+                                                    const float* __restrict__ v, const float* __restrict__ qp,
+                                                    const float* __restrict__ kpT, const float* __restrict__ vp,
+                                                    const float* __restrict__ bias, const float* __restrict__ z,
+                                                    const float* __restrict__ rots, const float* __restrict__ trans,
+                                                    const float* __restrict__ rmask, const float* __restrict__ head_w,
+                                                    float* __restrict__ cat, int B, int N, int layer) {
+    constexpr int CP = 128, HC = H * C, NQP = H * PQ * 3, NPT = H * PV * 3, NCAT = HC + H * PV * 4 + H * CP;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int NP8 = (N + 7) & ~7;
+    float* att = sm;                            // [H][NP8], zero padded
+    float* scr = sm + H * NP8;                  // q | q_pts | hw ; later red[4][H][CP]
+    float* opt = scr + 4 * H * CP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.x, b = row / N, i = row % N;
+    float* sq = scr;
+    float* sqp = scr + HC;
+    float* shw = sqp + NQP;
+    for (int u = tid; u < HC; u += 256) sq[u] = proj[(size_t)row * ldp + u];
+    for (int u = tid; u < NQP; u += 256) sqp[u] = qp[(size_t)row * NQP + u];
+    if (tid < H) {
+        const float g = head_w[tid];
+        const float sp = (g > 20.f) ? g : log1pf(expf(g));
+        shw[tid] = sp * sqrtf(1.0f / (3.0f * ((float)PQ * 9.0f / 2.0f)));
+    }
+    __syncthreads();
+    const float s_qk = sqrtf(1.0f / (3.0f * (float)C)), s_b = sqrtf(1.0f / 3.0f);
+    const float mi = rmask[row];
+    for (int j = tid; j < NP8; j += 256) {
+        const int jc = min(j, N - 1);
+        const float sqm = 1e5f * (mi * rmask[b * N + jc] - 1.0f);
+        float bia[H];
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) bia[hh] = bias[((((size_t)layer * H + hh) * B + b) * N + i) * N + jc];
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) {
+            const float* kc = kT + (((size_t)b * H + hh) * C) * N + jc;
+            float kv[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) kv[c] = kc[(size_t)c * N];
+            const float* kp = kpT + ((((size_t)b * H + hh) * PQ) * 3) * N + jc;
+            float kpv[PQ * 3];
+#pragma unroll
+            for (int c = 0; c < PQ * 3; ++c) kpv[c] = kp[(size_t)c * N];
+            float qk = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) qk += sq[hh * C + c] * kv[c];
+            float a = qk * s_qk;
+            a += s_b * bia[hh];
+            float pt = 0.f;
+#pragma unroll
+            for (int pp = 0; pp < PQ; ++pp) {
+                const float dx = sqp[(hh * PQ + pp) * 3 + 0] - kpv[pp * 3 + 0];
+                const float dy = sqp[(hh * PQ + pp) * 3 + 1] - kpv[pp * 3 + 1];
+                const float dz = sqp[(hh * PQ + pp) * 3 + 2] - kpv[pp * 3 + 2];
+                pt += ((dx * dx + dy * dy) + dz * dz) * shw[hh];
+            }
+            a += pt * (-0.5f);
+            a += sqm;
+            att[hh * NP8 + j] = (j < N) ? a : -3.0e38f;
+        }
+    }
+    __syncthreads();
+    for (int hh = wave; hh < H; hh += 4) {
+        float* ar = att + hh * NP8;
+        float mx = -3.0e38f;
+        for (int j = lane; j < N; j += 64) mx = fmaxf(mx, ar[j]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float s = 0.f;
+        for (int j = lane; j < N; j += 64) { const float e = expf(ar[j] - mx); ar[j] = e; s += e; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        for (int j = lane; j < NP8; j += 64) ar[j] = (j < N) ? ar[j] / s : 0.f;
+    }
+    __syncthreads();
+    float* crow = cat + (size_t)row * NCAT;
+    // o and o_pt: 480 outputs, 2 per thread, j unrolled x8 (weights: two ds_read_b128, values: 8 loads in flight)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int u = tid + 256 * half;
+        if (u < HC + NPT) {
+            const bool is_o = u < HC;
+            const int w = is_o ? u : u - HC;
+            const float* ar = att + (is_o ? (u / C) : (w / (PV * 3))) * NP8;
+            const float* vv = is_o ? v + (size_t)b * N * HC + u : vp + (size_t)b * N * NPT + w;
+            const int ld = is_o ? HC : NPT;
+            float acc = 0.f;
+            for (int j0 = 0; j0 < NP8; j0 += 8) {
+                float xv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) xv[k] = vv[(size_t)min(j0 + k, N - 1) * ld];
+                const float4 a0 = *reinterpret_cast<const float4*>(ar + j0);
+                const float4 a1 = *reinterpret_cast<const float4*>(ar + j0 + 4);
+                acc += a0.x * xv[0]; acc += a0.y * xv[1]; acc += a0.z * xv[2]; acc += a0.w * xv[3];
+                acc += a1.x * xv[4]; acc += a1.y * xv[5]; acc += a1.z * xv[6]; acc += a1.w * xv[7];
+            }
+            if (is_o) crow[u] = acc; else opt[w] = acc;
+        }
+    }
+    // o_pair: thread = (channel quad c4, j-group jg of 8); the p row is streamed once
+    {
+        const int c4 = tid & 31, jg = tid >> 5;
+        float4 acc[H];
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) acc[hh] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* zr = z + ((size_t)row * N) * CP + c4 * 4;
+        for (int j0 = jg; j0 < N; j0 += 32) {        // 4 rows (j0, j0+8, j0+16, j0+24) in flight
+            float4 zz[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) zz[k] = *reinterpret_cast<const float4*>(zr + (size_t)min(j0 + 8 * k, N - 1) * CP);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = j0 + 8 * k;
+                if (j < N) {
+#pragma unroll
+                    for (int hh = 0; hh < H; ++hh) {
+                        const float a = att[hh * NP8 + j];
+                        acc[hh].x += a * zz[k].x; acc[hh].y += a * zz[k].y; acc[hh].z += a * zz[k].z; acc[hh].w += a * zz[k].w;
+                    }
+                }
+            }
+        }
+        // merge the two half-waves (jg even / odd share a wave), then one LDS slab per wave
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) {
+            acc[hh].x += __shfl_xor(acc[hh].x, 32); acc[hh].y += __shfl_xor(acc[hh].y, 32);
+            acc[hh].z += __shfl_xor(acc[hh].z, 32); acc[hh].w += __shfl_xor(acc[hh].w, 32);
+        }
+        __syncthreads();     // q / q_pts scratch is dead: reuse as red
+        if (lane < 32) {
+#pragma unroll
+            for (int hh = 0; hh < H; ++hh) *reinterpret_cast<float4*>(scr + ((size_t)wave * H + hh) * CP + c4 * 4) = acc[hh];
+        }
+    }
+    __syncthreads();
+    {
+        float* op = crow + HC + H * PV * 4;
+        constexpr int tot = H * CP;
+        for (int u = tid; u < tot; u += 256) op[u] = (scr[u] + scr[tot + u]) + (scr[2 * tot + u] + scr[3 * tot + u]);
+    }
+    {
+        constexpr int np = H * PV;
+        const float* R = rots + (size_t)row * 9;
+        const float* t = trans + (size_t)row * 3;
+        for (int u = tid; u < np; u += 256) {
+            const float x = opt[u * 3 + 0] - t[0], y = opt[u * 3 + 1] - t[1], zc = opt[u * 3 + 2] - t[2];
+            const float lx = R[0] * x + R[3] * y + R[6] * zc;
+            const float ly = R[1] * x + R[4] * y + R[7] * zc;
+            const float lz = R[2] * x + R[5] * y + R[8] * zc;
+            crow[HC + u] = lx;
+            crow[HC + np + u] = ly;
+            crow[HC + 2 * np + u] = lz;
+            crow[HC + 3 * np + u] = sqrtf(((lx * lx + ly * ly) + lz * lz) + 1e-8f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Backbone update + frame composition (modules/backbone_update.py:40-66,
 // affine_utils.py:109-116,299-334), one wave per residue:
 //   [b c d | t] = W s + bias; q = (1,b,c,d)/sqrt(1+b^2+c^2+d^2);
@@ -507,7 +676,14 @@ void launch_ipa_prep(genie_ctx* h, hipStream_t st) {
                        h->kpT, h->vp, h->N, d.n_head_ipa, d.c_hidden_ipa, d.n_qk_point, d.n_v_point);
 }
 
+static bool ipa_is_base(const genie_dims_t& d) {
+    return d.n_head_ipa == 12 && d.c_hidden_ipa == 16 && d.n_qk_point == 4 && d.n_v_point == 8 && d.c_p == 128;
+}
+static size_t ipa_attn_t_lds(const genie_dims_t& d, int N) {
+    return ((size_t)d.n_head_ipa * ((N + 7) & ~7) + 4 * d.n_head_ipa * d.c_p + d.n_head_ipa * d.n_v_point * 3) * sizeof(float);
+}
 size_t ipa_attn_lds(const genie_dims_t& d, int N) {
+    if (ipa_is_base(d)) return ipa_attn_t_lds(d, N);
     return ((size_t)d.n_head_ipa * N + 8 * d.n_head_ipa * d.c_p + d.n_head_ipa * d.n_v_point * 3) * sizeof(float);
 }
 
@@ -515,6 +691,12 @@ void launch_ipa_attn(genie_ctx* h, hipStream_t st, int layer, const float* head_
     ProfScope ps(h, st, KC_IPA_ATTN);
     const genie_dims_t& d = h->d;
     const int ldp = d.n_head_ipa * (3 * d.c_hidden_ipa + 3 * d.n_qk_point + 3 * (d.n_qk_point + d.n_v_point));
+    if (ipa_is_base(d)) {
+        hipLaunchKernelGGL((k_ipa_attn_t<12, 16, 4, 8>), dim3(h->B * h->N), dim3(256), ipa_attn_t_lds(d, h->N), st, h->proj, ldp,
+                           h->kT, h->v, h->qp, h->kpT, h->vp, h->ipa_bias, h->p, h->rots_w, h->trans_w, h->rmaskf, head_w, h->cat,
+                           h->B, h->N, layer);
+        return;
+    }
     hipLaunchKernelGGL(k_ipa_attn, dim3(h->B * h->N), dim3(256), ipa_attn_lds(d, h->N), st, h->proj, ldp, h->kT, h->v, h->qp,
                        h->kpT, h->vp, h->ipa_bias, h->p, h->rots_w, h->trans_w, h->rmaskf, head_w, h->cat, h->B, h->N,
                        d.n_head_ipa, d.c_hidden_ipa, d.n_qk_point, d.n_v_point, d.c_p, layer);
@@ -554,6 +736,10 @@ void launch_scale_copy(genie_ctx* h, hipStream_t st, const float* in, float* out
 }
 
 void single_kernels_init(const genie_dims_t& d, int n_max) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)ipa_attn_lds(d, n_max));
+    if (ipa_is_base(d))
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn_t<12, 16, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)ipa_attn_t_lds(d, n_max));
+    else
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)ipa_attn_lds(d, n_max));
 }
