@@ -92,7 +92,7 @@ int genie_create(const genie_dims_t* dims, int device, genie_handle_t* out) {
     memset(h, 0, sizeof(*h));
     h->d = *dims;
     h->device = device;
-    { const char* e = getenv("GENIE_PAIR_TILE_MASK"); h->pair_impl = e ? atoi(e) : 2; }
+    { const char* e = getenv("GENIE_PAIR_TILE_MASK"); h->pair_impl = e ? atoi(e) : 0; }
     if (hipSetDevice(device) != hipSuccess) { delete h; snprintf(g_create_err, sizeof g_create_err, "hipSetDevice failed"); return GENIE_E_HIP; }
     h->pair = new PairLayerW[dims->n_pair_transform_layer > 0 ? dims->n_pair_transform_layer : 1]();
     h->st = new StructLayerW[dims->n_structure_layer]();
@@ -153,6 +153,16 @@ struct Cur {
     const float* p; size_t left;
     const float* take(size_t n) { if (n > left) { left = 0; return nullptr; } const float* r = p; p += n; left -= n; return r; }
 };
+// LayerNorm affine folded into the Linear that consumes it:  W (g * xhat + beta) + b = (W diag g) xhat + (b + W beta).
+// The kernels then only normalise (no gamma / beta traffic or FMAs per tile).  Sums in double.
+void fold_ln(std::vector<float>& W, std::vector<float>& b, int rows, int cols, const float* g, const float* beta) {
+    for (int r = 0; r < rows; ++r) {
+        double acc = b[r];
+        for (int k = 0; k < cols; ++k) acc += (double)W[(size_t)r * cols + k] * beta[k];
+        b[r] = (float)acc;
+        for (int k = 0; k < cols; ++k) W[(size_t)r * cols + k] *= g[k];
+    }
+}
 std::vector<float> vcat(std::initializer_list<std::pair<const float*, size_t>> parts) {
     std::vector<float> v;
     for (auto& pr : parts) v.insert(v.end(), pr.first, pr.first + pr.second);
@@ -174,6 +184,12 @@ int genie_load_weights(genie_handle_t h, const float* blob, size_t n_floats) {
     std::vector<std::pair<float**, size_t>> fix;     // (pointer slot, offset)
     auto slot = [&](float** s, size_t off) { fix.push_back({s, off}); };
 
+    size_t ones_off, zeros_off;
+    {
+        std::vector<float> one(512, 1.f), zero(512, 0.f);
+        ones_off = img.raw(one.data(), one.size());
+        zeros_off = img.raw(zero.data(), zero.size());
+    }
     const int nsi = single_in(d);
     slot(&h->single_w, img.pack(c.take(cs * nsi), (int)cs, nsi));
     {
@@ -215,19 +231,33 @@ int genie_load_weights(genie_handle_t h, const float* blob, size_t n_floats) {
             const float* lo_g = c.take(ch); const float* lo_b = c.take(ch);
             auto w = vcat({{ap_w, ch * cp}, {bp_w, ch * cp}, {ag_w, ch * cp}, {bg_w, ch * cp}});
             auto bb = vcat({{ap_b, ch}, {bp_b, ch}, {ag_b, ch}, {bg_b, ch}});
+            fold_ln(w, bb, (int)(4 * ch), (int)cp, li_g, li_b);
+            // gate halves (rows 2ch..4ch) pre-scaled by -log2(e): sigmoid(x) = 1 / (1 + exp2(x')) in the kernel
+            for (size_t r = 2 * ch; r < 4 * ch; ++r) {
+                bb[r] = (float)(-1.4426950408889634 * bb[r]);
+                for (size_t k = 0; k < cp; ++k) w[r * cp + k] = (float)(-1.4426950408889634 * w[r * cp + k]);
+            }
+            std::vector<float> gw(g_w, g_w + cp * cp), gb(g_b, g_b + cp), zw(z_w, z_w + cp * ch), zb(z_b, z_b + cp);
+            fold_ln(gw, gb, (int)cp, (int)cp, li_g, li_b);
+            fold_ln(zw, zb, (int)cp, (int)ch, lo_g, lo_b);
             slot(&T.proj_w, img.pack(w.data(), (int)(4 * ch), (int)cp));
             slot(&T.proj_b, img.raw(bb.data(), bb.size()));
-            slot(&T.g_w, img.pack(g_w, (int)cp, (int)cp)); slot(&T.g_b, img.raw(g_b, cp));
-            slot(&T.z_w, img.pack(z_w, (int)cp, (int)ch)); slot(&T.z_b, img.raw(z_b, cp));
-            slot(&T.ln_in_g, img.raw(li_g, cp)); slot(&T.ln_in_b, img.raw(li_b, cp));
-            slot(&T.ln_out_g, img.raw(lo_g, ch)); slot(&T.ln_out_b, img.raw(lo_b, ch));
+            slot(&T.g_w, img.pack(gw.data(), (int)cp, (int)cp)); slot(&T.g_b, img.raw(gb.data(), cp));
+            slot(&T.z_w, img.pack(zw.data(), (int)cp, (int)ch)); slot(&T.z_b, img.raw(zb.data(), cp));
+            // the affine now lives in the weights: kernels that still take gamma / beta get (1, 0)
+            slot(&T.ln_in_g, ones_off); slot(&T.ln_in_b, zeros_off);
+            slot(&T.ln_out_g, ones_off); slot(&T.ln_out_b, zeros_off);
         }
         const size_t nh = (size_t)d.pair_transition_n * cp;
         const float* lg = c.take(cp); const float* lb = c.take(cp);
         const float* w1 = c.take(nh * cp); const float* b1 = c.take(nh);
         const float* w2 = c.take(cp * nh); const float* b2 = c.take(cp);
-        slot(&L.pt_ln_g, img.raw(lg, cp)); slot(&L.pt_ln_b, img.raw(lb, cp));
-        slot(&L.pt_w1, img.pack(w1, (int)nh, (int)cp)); slot(&L.pt_b1, img.raw(b1, nh));
+        {
+            std::vector<float> w1v(w1, w1 + nh * cp), b1v(b1, b1 + nh);
+            fold_ln(w1v, b1v, (int)nh, (int)cp, lg, lb);
+            slot(&L.pt_ln_g, ones_off); slot(&L.pt_ln_b, zeros_off);
+            slot(&L.pt_w1, img.pack(w1v.data(), (int)nh, (int)cp)); slot(&L.pt_b1, img.raw(b1v.data(), nh));
+        }
         slot(&L.pt_w2, img.pack(w2, (int)cp, (int)nh)); slot(&L.pt_b2, img.raw(b2, cp));
     }
     const size_t H = d.n_head_ipa, C = d.c_hidden_ipa, Pq = d.n_qk_point, Pv = d.n_v_point;

@@ -5,12 +5,7 @@
 
 #define LDZ 132   // 128-channel tile row stride (floats): conflict-free ds_read_b128
 #define LDX 68    // 64-wide M-contiguous tile row stride
-#ifndef PROJ_PD
-#define PROJ_PD 4
-#endif
-#ifndef PROJ_OCC
-#define PROJ_OCC 3
-#endif
+
 
 // Load 64 pair rows x 128 channels (row t at src + t*row_stride) into tile[64][LDZ].
 __device__ __forceinline__ void load_tile64(float* tile, const float* __restrict__ src, size_t row_stride,
@@ -35,93 +30,6 @@ __device__ __forceinline__ void load_tile64(float* tile, const float* __restrict
 }
 
 // ---------------------------------------------------------------------------
-// Triangle multiplication, projections
-// (modules/triangular_multiplicative_update.py:99-103):
-//   zn = LN_in(z); a = (W_ap zn + b)*sigmoid(W_ag zn + b)*mask; b likewise.
-// Output is channel-major a_cm[b][c][line][pos] (pos contiguous) so that the
-// contraction is one "NT" batched GEMM for both directions:
-//   outgoing: tile = row i of z,   line = i, pos = k = j    (a[i,k,c])
-//   incoming: tile = column j of z, line = j, pos = k = i   (a[k,i,c] stored as aT[i][k])
-// MFMA orientation: D rows = channels (A operand = W), D cols = pairs (lanes),
-// which makes every store a 128-B run.
-// ---------------------------------------------------------------------------
-template <bool OUTGOING>
-__global__ __launch_bounds__(256, PROJ_OCC) void k_trimul_proj(const float* __restrict__ z, const float* __restrict__ rmask,
-                                                     const float* __restrict__ wp, const float* __restrict__ bias,
-                                                     const float* __restrict__ lng, const float* __restrict__ lnb,
-                                                     float* __restrict__ acm, float* __restrict__ bcm, int N, int NP) {
-    __shared__ __attribute__((aligned(16))) float zt[64 * LDZ];
-    __shared__ float msk[64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ntile = (N + 63) >> 6;
-    const int st = blockIdx.x % ntile;
-    const int line = (blockIdx.x / ntile) % N;
-    const int b = blockIdx.x / (ntile * N);
-    const int t0 = st * 64;
-    const int nvalid = min(64, N - t0);
-    const float* src;
-    size_t stride;
-    if (OUTGOING) { src = z + (((size_t)b * N + line) * N + t0) * 128; stride = 128; }
-    else          { src = z + (((size_t)b * N + t0) * N + line) * 128; stride = (size_t)N * 128; }
-    load_tile64(zt, src, stride, nvalid, tid);
-    if (tid < 64) msk[tid] = (tid < nvalid) ? rmask[b * N + line] * rmask[b * N + t0 + tid] : 0.f;
-    __syncthreads();
-    ln_rows_128(zt, LDZ, lng, lnb, tid);
-    __syncthreads();
-
-    // Weight fragments run PROJ_PD k-blocks (PROJ_PD x 1024 MFMA cycles) ahead of the MFMAs in a
-    // rotating register ring (common.h, "software-pipelined weight fragments"); the ring is kept
-    // full across the two channel-group passes, so only the very first fill is exposed.
-    v4f wq[PROJ_PD][2];
-#pragma unroll
-    for (int s = 0; s < PROJ_PD; ++s) {
-        wf_issue(wq[s][0], wfrag_ptr(wp, 16, wave, s, lane));
-        wf_issue(wq[s][1], wfrag_ptr(wp, 16, 8 + wave, s, lane));
-    }
-    for (int it = 0; it < 2; ++it) {
-        const int cg = wave + 4 * it;          // 0..3 -> a channels, 4..7 -> b channels
-        const int nb_p = cg, nb_g = 8 + cg;
-        f32x16 ap0 = zero16(), ap1 = zero16(), ag0 = zero16(), ag1 = zero16();
-#pragma unroll 1
-        for (int kb0 = 0; kb0 < 16; kb0 += PROJ_PD) {
-#pragma unroll
-            for (int s = 0; s < PROJ_PD; ++s) {
-                const int kb = kb0 + s;
-                const float4 z0 = lfrag(zt, LDZ, 0, kb, lane);
-                const float4 z1 = lfrag(zt, LDZ, 32, kb, lane);
-                wf_wait<2 * (PROJ_PD - 1)>(wq[s][0], wq[s][1]);
-                ap0 = mfma_8k(wq[s][0], z0, ap0);
-                ap1 = mfma_8k(wq[s][0], z1, ap1);
-                ag0 = mfma_8k(wq[s][1], z0, ag0);
-                ag1 = mfma_8k(wq[s][1], z1, ag1);
-                __builtin_amdgcn_sched_barrier(0);
-                // refill slot s: k-block kb + PD of this pass, or the head of the next pass
-                // (past the very end: a harmless re-load that keeps the in-flight count uniform)
-                int kn = kb + PROJ_PD, np = nb_p, ng = nb_g;
-                if (kn >= 16) { if (it == 0) { kn -= 16; np += 4; ng += 4; } else { kn = 15; } }
-                wf_issue(wq[s][0], wfrag_ptr(wp, 16, np, kn, lane));
-                wf_issue(wq[s][1], wfrag_ptr(wp, 16, ng, kn, lane));
-            }
-        }
-        if (it == 1) {    // retire the ring before its registers are reused
-#pragma unroll
-            for (int s = 0; s < PROJ_PD; ++s) wf_wait<0>(wq[s][0], wq[s][1]);
-        }
-        float* dst = (cg < 4) ? acm : bcm;
-        const int chbase = (cg & 3) * 32;
-        const int t_lo = lane & 31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = acc_row(r, lane);
-            const float bp = bias[nb_p * 32 + row], bg = bias[nb_g * 32 + row];
-            float* drow = dst + (((size_t)b * 128 + chbase + row) * NP + line) * NP + t0;
-            if (t_lo < nvalid) drow[t_lo] = (ap0[r] + bp) * sigmoidf_(ag0[r] + bg) * msk[t_lo];
-            if (t_lo + 32 < nvalid) drow[t_lo + 32] = (ap1[r] + bp) * sigmoidf_(ag1[r] + bg) * msk[t_lo + 32];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
 // Triangle multiplication, contraction (trimul :57-82):
 //   x_cm[bc][i][j] = sum_k a_cm[bc][i][k] * b_cm[bc][j][k]   for bc = b*C + c.
 // WG tile (64*WT)^2, 4 waves of (32*WT)^2, K streamed in 32-wide chunks through
@@ -130,14 +38,21 @@ __global__ __launch_bounds__(256, PROJ_OCC) void k_trimul_proj(const float* __re
 #define LDK 36
 template <int WT>
 __global__ __launch_bounds__(256) void k_trimul_contract(const float* __restrict__ acm, const float* __restrict__ bcm,
-                                                         float* __restrict__ xcm, int NP) {
+                                                         float* __restrict__ xcm, int NP, int n_mat) {
     constexpr int TM = 64 * WT;
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [2 buf][A|B][TM*LDK]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware decode: work-groups are dealt round-robin over the 8 XCDs, so the T tiles of one
+    // (b, c) matrix take ids with equal id % 8 and sit 8 apart: they run on ONE XCD at about the
+    // same time and share each A / B panel through that XCD's L2 (placement affects speed only).
     const int tiles = (NP + TM - 1) / TM;
-    const int i0 = (blockIdx.x / tiles) * TM, j0 = (blockIdx.x % tiles) * TM;
-    const size_t mat = (size_t)blockIdx.y * NP * NP;
+    const int T = tiles * tiles;
+    const int grp = blockIdx.x / (8 * T), rem = blockIdx.x % (8 * T);
+    const int tile = rem >> 3, mi = grp * 8 + (rem & 7);
+    if (mi >= n_mat) return;
+    const int i0 = (tile / tiles) * TM, j0 = (tile % tiles) * TM;
+    const size_t mat = (size_t)mi * NP * NP;
     const float* A = acm + mat;
     const float* Bm = bcm + mat;
     const int lr = tid >> 3, c4 = tid & 7;
@@ -648,23 +563,15 @@ void launch_pair_init(genie_ctx* h, hipStream_t st, const float* trans, const fl
                        h->d.template_dist_n_bin);
 }
 
-void launch_trimul_proj_wi(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgoing);
-void launch_trimul_out_wi(genie_ctx* h, hipStream_t st, const TriMulW& w);
-void launch_pair_transition_wi(genie_ctx* h, hipStream_t st, const PairLayerW& w);
+void launch_trimul_proj_wl(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgoing);
+void launch_trimul_out_wl(genie_ctx* h, hipStream_t st, const TriMulW& w);
+void launch_pair_transition_wl(genie_ctx* h, hipStream_t st, const PairLayerW& w);
 
 void launch_trimul(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgoing) {
     const int N = h->N, NP = h->NP, ntile = (N + 63) / 64;
     {
         ProfScope ps(h, st, KC_TRIMUL_PROJ);
-        dim3 grid(h->B * N * ntile);
-        if (!(h->pair_impl & 1))
-            launch_trimul_proj_wi(h, st, w, outgoing);
-        else if (outgoing)
-            hipLaunchKernelGGL(k_trimul_proj<true>, grid, dim3(256), 0, st, h->p, h->rmaskf, w.proj_w, w.proj_b, w.ln_in_g,
-                               w.ln_in_b, h->acm, h->bcm, N, NP);
-        else
-            hipLaunchKernelGGL(k_trimul_proj<false>, grid, dim3(256), 0, st, h->p, h->rmaskf, w.proj_w, w.proj_b, w.ln_in_g,
-                               w.ln_in_b, h->acm, h->bcm, N, NP);
+        launch_trimul_proj_wl(h, st, w, outgoing);
     }
     {
         ProfScope ps(h, st, KC_TRIMUL_CONTRACT);
@@ -672,17 +579,19 @@ void launch_trimul(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgoing
         if (NP >= 128) {
             const int tiles = (NP + 127) / 128;
             const size_t lds = 2 * 2 * 128 * LDK * sizeof(float);
-            hipLaunchKernelGGL(k_trimul_contract<2>, dim3(tiles * tiles, BC), dim3(256), lds, st, h->acm, h->bcm, h->xcm, NP);
+            hipLaunchKernelGGL(k_trimul_contract<2>, dim3(tiles * tiles * ((BC + 7) / 8) * 8), dim3(256), lds, st, h->acm, h->bcm,
+                               h->xcm, NP, BC);
         } else {
             const int tiles = (NP + 63) / 64;
             const size_t lds = 2 * 2 * 64 * LDK * sizeof(float);
-            hipLaunchKernelGGL(k_trimul_contract<1>, dim3(tiles * tiles, BC), dim3(256), lds, st, h->acm, h->bcm, h->xcm, NP);
+            hipLaunchKernelGGL(k_trimul_contract<1>, dim3(tiles * tiles * ((BC + 7) / 8) * 8), dim3(256), lds, st, h->acm, h->bcm,
+                               h->xcm, NP, BC);
         }
     }
     {
         ProfScope ps(h, st, KC_TRIMUL_OUT);
         if (!(h->pair_impl & 2))
-            launch_trimul_out_wi(h, st, w);
+            launch_trimul_out_wl(h, st, w);
         else
             hipLaunchKernelGGL(k_trimul_out, dim3(h->B * N * ntile), dim3(256), 0, st, h->p, h->xcm, w.g_w, w.g_b, w.z_w, w.z_b,
                            w.ln_in_g, w.ln_in_b, w.ln_out_g, w.ln_out_b, N, NP);
@@ -691,7 +600,7 @@ void launch_trimul(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgoing
 
 void launch_pair_transition(genie_ctx* h, hipStream_t st, const PairLayerW& w) {
     ProfScope ps(h, st, KC_PAIR_TRANSITION);
-    if (!(h->pair_impl & 4)) { launch_pair_transition_wi(h, st, w); return; }
+    if (!(h->pair_impl & 4)) { launch_pair_transition_wl(h, st, w); return; }
     const long long M = (long long)h->B * h->N * h->N;
     const size_t lds = (2 * 64 * LDZ + 64) * sizeof(float);
     hipLaunchKernelGGL(k_pair_transition, dim3((unsigned)((M + 63) / 64)), dim3(256), lds, st, h->p, h->rmaskf, w.pt_ln_g,
@@ -707,8 +616,10 @@ void launch_ipa_bias(genie_ctx* h, hipStream_t st) {
                        h->B, N, LH);
 }
 
+void pair_wl_kernels_init();
 // One-time opt-in to > 64 KiB dynamic LDS.
 void pair_kernels_init() {
+    pair_wl_kernels_init();
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_trimul_contract<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         2 * 2 * 128 * LDK * sizeof(float));
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_transition), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -43,47 +43,70 @@ __global__ void k_single_input(float* __restrict__ x, int ldx, const float* __re
 // B*N: single feature net, p_i/p_j, IPA projections and output, transition.
 // ---------------------------------------------------------------------------
 #define LDA 68
+#define GR_PD 8
 __global__ __launch_bounds__(256) void k_gemm_rows(const float* __restrict__ A, int lda, int M, int K,
                                                    const float* __restrict__ Wp, int Nout,
                                                    const float* __restrict__ bias, const float* __restrict__ res, int ldr,
                                                    const float* __restrict__ rowmask, int relu, float* __restrict__ out, int ldo) {
+    // Every global load of the main loop is an asm load (common.h, "software-pipelined weight
+    // fragments"): the weight ring stays GR_PD k-blocks ahead, the next A chunk is in flight
+    // during the current chunk's MFMAs, and no compiler-inserted vmcnt(0) drains either.
+    // In-order retirement makes the wait counts static:
+    //   releasing ring slot kb : younger = (7-kb) old slots + 2 A loads + kb refills  = GR_PD + 1
+    //   releasing the A loads  : younger = the 8 refills of this chunk                = GR_PD
     __shared__ __attribute__((aligned(16))) float sa[2][32 * LDA];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = blockIdx.x * 32;
-    const int nb = blockIdx.y * 4 + wave;
+    const int nb = min((int)(blockIdx.y * 4 + wave), (Nout + 31) / 32 - 1);   // idle waves shadow the last block
+    const bool active = (int)(blockIdx.y * 4 + wave) * 32 < Nout;
     const int KB = (K + 7) >> 3;
     const int nkc = (K + 63) >> 6;
-    const bool active = nb * 32 < Nout;
     const int lr = tid >> 4, c4 = tid & 15;      // 16 rows x 16 float4 per pass, 2 passes
-    float4 ra[2];
-    auto gload = [&](int kc) {
+    const float* wbase = Wp + ((size_t)nb * KB * 64 + lane) * 4;
+
+    v4f wq[GR_PD];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int r = r0 + lr + 16 * u, k = kc * 64 + c4 * 4;
-            // unconditional load from a clamped address, zeroed afterwards: keeps both loads in flight
-            const float4 t = *reinterpret_cast<const float4*>(A + (size_t)min(r, M - 1) * lda + min(k, K - 4));
-            ra[u] = (r < M && k < K) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    for (int s = 0; s < GR_PD; ++s) wf_issue(wq[s], wbase + (size_t)min(s, KB - 1) * 256);
+
+    v4f ra0, ra1;
+    auto a_addr = [&](int kc, int u) {
+        const int r = min(r0 + lr + 16 * u, M - 1), k = min(kc * 64 + c4 * 4, K - 4);
+        return A + (size_t)r * lda + k;
     };
-    auto swrite = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) *reinterpret_cast<float4*>(&sa[buf][(lr + 16 * u) * LDA + c4 * 4]) = ra[u];
+    auto a_store = [&](int kc, int buf) {
+        const bool kok = kc * 64 + c4 * 4 < K;
+        const v4f z4 = {0.f, 0.f, 0.f, 0.f};
+        const v4f v0 = (kok && r0 + lr < M) ? ra0 : z4;
+        const v4f v1 = (kok && r0 + lr + 16 < M) ? ra1 : z4;
+        *reinterpret_cast<v4f*>(&sa[buf][lr * LDA + c4 * 4]) = v0;
+        *reinterpret_cast<v4f*>(&sa[buf][(lr + 16) * LDA + c4 * 4]) = v1;
     };
-    f32x16 acc = zero16();
-    gload(0);
-    swrite(0);
+    wf_issue(ra0, a_addr(0, 0));
+    wf_issue(ra1, a_addr(0, 1));
+    wf_wait<0>(ra0, ra1);
+    a_store(0, 0);
     __syncthreads();
+
+    f32x16 acc = zero16();
     for (int kc = 0; kc < nkc; ++kc) {
-        if (kc + 1 < nkc) gload(kc + 1);
-        if (active) {
-            const int kbn = min(8, KB - kc * 8);
-#pragma unroll 4
-            for (int kb = 0; kb < kbn; ++kb)
-                acc = mfma_8k(lfrag(sa[kc & 1], LDA, 0, kb, lane), wfrag(Wp, KB, nb, kc * 8 + kb, lane), acc);
+        const int kcn = min(kc + 1, nkc - 1);            // last chunk: harmless re-load keeps the counts uniform
+        wf_issue(ra0, a_addr(kcn, 0));
+        wf_issue(ra1, a_addr(kcn, 1));
+        const float* cur = sa[kc & 1];
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            const float4 af = lfrag(cur, LDA, 0, kb, lane);
+            wf_wait<GR_PD + 1>(wq[kb]);
+            if (kc * 8 + kb < KB) acc = mfma_8k(af, wq[kb], acc);
+            __builtin_amdgcn_sched_barrier(0);
+            wf_issue(wq[kb], wbase + (size_t)min(kc * 8 + kb + GR_PD, KB - 1) * 256);
         }
-        if (kc + 1 < nkc) swrite((kc + 1) & 1);
+        wf_wait<GR_PD>(ra0, ra1);
+        a_store(kcn, (kc + 1) & 1);
         __syncthreads();
     }
+#pragma unroll
+    for (int s = 0; s < GR_PD; ++s) wf_wait<0>(wq[s]);
     if (!active) return;
     const int col = nb * 32 + (lane & 31);
     if (col >= Nout) return;
