@@ -177,8 +177,6 @@ struct StructLayerW {
 struct genie_ctx {
     genie_dims_t d;
     int device;
-    int pair_impl;                // bit set = first-generation LDS-tile kernel, clear = WL kernel (pair_wl_kernels.hip);
-                                  // bit 0 trimul_proj, 1 trimul_out, 2 pair_transition (GENIE_PAIR_TILE_MASK, default 0)
     char err[512];
 
     // weights

@@ -92,7 +92,6 @@ int genie_create(const genie_dims_t* dims, int device, genie_handle_t* out) {
     memset(h, 0, sizeof(*h));
     h->d = *dims;
     h->device = device;
-    { const char* e = getenv("GENIE_PAIR_TILE_MASK"); h->pair_impl = e ? atoi(e) : 0; }
     if (hipSetDevice(device) != hipSuccess) { delete h; snprintf(g_create_err, sizeof g_create_err, "hipSetDevice failed"); return GENIE_E_HIP; }
     h->pair = new PairLayerW[dims->n_pair_transform_layer > 0 ? dims->n_pair_transform_layer : 1]();
     h->st = new StructLayerW[dims->n_structure_layer]();
@@ -239,6 +238,10 @@ int genie_load_weights(genie_handle_t h, const float* blob, size_t n_floats) {
             }
             std::vector<float> gw(g_w, g_w + cp * cp), gb(g_b, g_b + cp), zw(z_w, z_w + cp * ch), zb(z_b, z_b + cp);
             fold_ln(gw, gb, (int)cp, (int)cp, li_g, li_b);
+            for (size_t r = 0; r < cp; ++r) {       // gate pre-scaled by -log2(e), as above
+                gb[r] = (float)(-1.4426950408889634 * gb[r]);
+                for (size_t k = 0; k < cp; ++k) gw[r * cp + k] = (float)(-1.4426950408889634 * gw[r * cp + k]);
+            }
             fold_ln(zw, zb, (int)cp, (int)ch, lo_g, lo_b);
             slot(&T.proj_w, img.pack(w.data(), (int)(4 * ch), (int)cp));
             slot(&T.proj_b, img.raw(bb.data(), bb.size()));

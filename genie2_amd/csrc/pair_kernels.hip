@@ -1,10 +1,20 @@
-// Pair-track kernels: pair feature net, triangle multiplication, pair transition,
-// IPA pair bias.  All GEMMs are exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); see
-// common.h for the fragment convention.  Reference lines are cited per kernel.
+// Pair-track kernels: pair feature net, the triangle-multiplication contraction, IPA pair
+// bias (the row-tile GEMM kernels -- TriMul projections / output, pair transition -- live in
+// pair_wl_kernels.hip).  All GEMMs are exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); see common.h
+// for the fragment convention.  Reference lines are cited per kernel.
+//
+// TriMul data flow (modules/triangular_multiplicative_update.py:57-110):
+//   k_trimul_proj_wl : zn = LN_in(z); a = (W_ap zn + b) sigmoid(W_ag zn + b) mask; b likewise.
+//       Output channel-major a_cm[b][c][line][pos] (pos contiguous) so the contraction is ONE
+//       "NT" batched GEMM for both directions:
+//         outgoing: tile = row i of z,    line = i, pos = k = j   (a[i,k,c])
+//         incoming: tile = column j of z, line = j, pos = k = i   (a[k,i,c] stored as aT[i][k])
+//       MFMA orientation D rows = channels, D cols = pairs -> every store is a 128-B run.
+//   k_trimul_contract: x_cm[bc][i][j] = sum_k a_cm[bc][i][k] b_cm[bc][j][k]
+//   k_trimul_out_wl  : z += (W_z LN_out(x) + b_z) sigmoid(W_g LN_in(z) + b_g)
 #include "common.h"
 
 #define LDZ 132   // 128-channel tile row stride (floats): conflict-free ds_read_b128
-#define LDX 68    // 64-wide M-contiguous tile row stride
 
 
 // Load 64 pair rows x 128 channels (row t at src + t*row_stride) into tile[64][LDZ].
@@ -120,179 +130,6 @@ __global__ __launch_bounds__(256) void k_trimul_contract(const float* __restrict
                 if (i < NP && j < NP) X[(size_t)i * NP + j] = acc[m][n][r];
             }
         }
-}
-
-// ---------------------------------------------------------------------------
-// Triangle multiplication, output (trimul :105-108 + residual
-// pair_transform_net.py:111-112):
-//   z += (W_z LN_out(x) + b_z) * sigmoid(W_g LN_in(z) + b_g)
-// The gate is computed here from the z tile the residual needs anyway, so g
-// never goes through HBM.  x arrives channel-major and is consumed as an
-// M-contiguous LDS tile [c][j].
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 4) void k_trimul_out(float* __restrict__ z, const float* __restrict__ xcm,
-                                                    const float* __restrict__ wg, const float* __restrict__ bg,
-                                                    const float* __restrict__ wz, const float* __restrict__ bz,
-                                                    const float* __restrict__ ln_in_g, const float* __restrict__ ln_in_b,
-                                                    const float* __restrict__ ln_out_g, const float* __restrict__ ln_out_b,
-                                                    int N, int NP) {
-    __shared__ __attribute__((aligned(16))) float buf[128 * LDX];   // >= 64*LDZ
-    __shared__ float red[4][64];
-    __shared__ float st_mean[64], st_rstd[64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ntile = (N + 63) >> 6;
-    const int st = blockIdx.x % ntile;
-    const int i = (blockIdx.x / ntile) % N;
-    const int b = blockIdx.x / (ntile * N);
-    const int t0 = st * 64;
-    const int nvalid = min(64, N - t0);
-    float* zrow = z + (((size_t)b * N + i) * N + t0) * 128;
-
-    load_tile64(buf, zrow, 128, nvalid, tid);
-    __syncthreads();
-    ln_rows_128(buf, LDZ, ln_in_g, ln_in_b, tid);
-    __syncthreads();
-    f32x16 g0 = zero16(), g1 = zero16();
-#pragma unroll 4
-    for (int kb = 0; kb < 16; ++kb) {
-        const float4 w = wfrag(wg, 16, wave, kb, lane);
-        g0 = mfma_8k(lfrag(buf, LDZ, 0, kb, lane), w, g0);
-        g1 = mfma_8k(lfrag(buf, LDZ, 32, kb, lane), w, g1);
-    }
-    const int ch = wave * 32 + (lane & 31);
-    {
-        const float bgc = bg[ch];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { g0[r] = sigmoidf_(g0[r] + bgc); g1[r] = sigmoidf_(g1[r] + bgc); }
-    }
-    __syncthreads();   // everyone is done reading the z tile
-
-    // x tile: xt[c][j], c = 0..127, j = t0..t0+63
-    {
-        const int f4 = tid & 15;
-        const int j = t0 + 4 * f4;
-        float4 xv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int c = (tid >> 4) + 16 * u;
-            xv[u] = *reinterpret_cast<const float4*>(xcm + (((size_t)b * 128 + c) * NP + i) * NP + min(j, NP - 4));
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int c = (tid >> 4) + 16 * u;
-            if (j >= NP) xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(buf + c * LDX + 4 * f4) = xv[u];
-        }
-    }
-    __syncthreads();
-    // LN_out over c for each j (4 threads per j, 32 channels each)
-    {
-        const int j = tid & 63, part = tid >> 6;
-        float s = 0.f;
-#pragma unroll 8
-        for (int q = 0; q < 32; ++q) s += buf[(part * 32 + q) * LDX + j];
-        red[part][j] = s;
-        __syncthreads();
-        const float mean = (red[0][j] + red[1][j] + red[2][j] + red[3][j]) * (1.0f / 128.0f);
-        __syncthreads();
-        float ss = 0.f;
-#pragma unroll 8
-        for (int q = 0; q < 32; ++q) { const float d = buf[(part * 32 + q) * LDX + j] - mean; ss += d * d; }
-        red[part][j] = ss;
-        __syncthreads();
-        const float var = (red[0][j] + red[1][j] + red[2][j] + red[3][j]) * (1.0f / 128.0f);
-        const float rstd = 1.0f / sqrtf(var + GENIE_LN_EPS);
-#pragma unroll 8
-        for (int q = 0; q < 32; ++q) {
-            const int c = part * 32 + q;
-            buf[c * LDX + j] = (buf[c * LDX + j] - mean) * rstd * ln_out_g[c] + ln_out_b[c];
-        }
-    }
-    __syncthreads();
-    f32x16 a0 = zero16(), a1 = zero16();
-#pragma unroll 4
-    for (int kb = 0; kb < 16; ++kb) {
-        const float4 w = wfrag(wz, 16, wave, kb, lane);
-        a0 = mfma_8k(lfrag_t(buf, LDX, 0, kb, lane), w, a0);
-        a1 = mfma_8k(lfrag_t(buf, LDX, 32, kb, lane), w, a1);
-    }
-    const float bzc = bz[ch];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int t = acc_row(r, lane);
-        if (t < nvalid) { float* q = zrow + (size_t)t * 128 + ch; *q = (a0[r] + bzc) * g0[r] + *q; }
-        if (t + 32 < nvalid) { float* q = zrow + (size_t)(t + 32) * 128 + ch; *q = (a1[r] + bzc) * g1[r] + *q; }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Pair transition + end-of-layer mask (modules/pair_transition.py:48-56,
-// pair_transform_net.py:116-117):
-//   z = (z + mask * (W2 relu(W1 LN(z) + b1) + b2)) * mask
-// 64 rows per WG; the 512-wide hidden layer lives only in registers / LDS
-// (four 128-wide chunks).
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pair_transition(float* __restrict__ z, const float* __restrict__ rmask,
-                                                         const float* __restrict__ lng, const float* __restrict__ lnb,
-                                                         const float* __restrict__ w1, const float* __restrict__ b1,
-                                                         const float* __restrict__ w2, const float* __restrict__ b2,
-                                                         int N, long long M, int n_chunk) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* zt = sm;
-    float* ht = sm + 64 * LDZ;
-    float* msk = ht + 64 * LDZ;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long row0 = (long long)blockIdx.x * 64;
-    const int nvalid = (int)min((long long)64, M - row0);
-    float* zrow = z + row0 * 128;
-    load_tile64(zt, zrow, 128, nvalid, tid);
-    if (tid < 64) {
-        float m = 0.f;
-        if (tid < nvalid) {
-            const long long idx = row0 + tid;
-            const int b = (int)(idx / ((long long)N * N));
-            const int rem = (int)(idx - (long long)b * N * N);
-            m = rmask[b * N + rem / N] * rmask[b * N + rem % N];
-        }
-        msk[tid] = m;
-    }
-    __syncthreads();
-    ln_rows_128(zt, LDZ, lng, lnb, tid);
-    __syncthreads();
-    const int KB2 = n_chunk * 16;
-    f32x16 o0 = zero16(), o1 = zero16();
-    const int col = wave * 32 + (lane & 31);
-    for (int hc = 0; hc < n_chunk; ++hc) {
-        f32x16 h0 = zero16(), h1 = zero16();
-#pragma unroll 4
-        for (int kb = 0; kb < 16; ++kb) {
-            const float4 w = wfrag(w1, 16, hc * 4 + wave, kb, lane);
-            h0 = mfma_8k(lfrag(zt, LDZ, 0, kb, lane), w, h0);
-            h1 = mfma_8k(lfrag(zt, LDZ, 32, kb, lane), w, h1);
-        }
-        const float bb = b1[hc * 128 + col];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int t = acc_row(r, lane);
-            ht[t * LDZ + col] = fmaxf(h0[r] + bb, 0.f);
-            ht[(t + 32) * LDZ + col] = fmaxf(h1[r] + bb, 0.f);
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int kb = 0; kb < 16; ++kb) {
-            const float4 w = wfrag(w2, KB2, wave, hc * 16 + kb, lane);
-            o0 = mfma_8k(lfrag(ht, LDZ, 0, kb, lane), w, o0);
-            o1 = mfma_8k(lfrag(ht, LDZ, 32, kb, lane), w, o1);
-        }
-        __syncthreads();
-    }
-    const float b2c = b2[col];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int t = acc_row(r, lane);
-        if (t < nvalid) { float* q = zrow + (size_t)t * 128 + col; const float m = msk[t]; *q = ((o0[r] + b2c) * m + *q) * m; }
-        if (t + 32 < nvalid) { float* q = zrow + (size_t)(t + 32) * 128 + col; const float m = msk[t + 32]; *q = ((o1[r] + b2c) * m + *q) * m; }
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -590,21 +427,13 @@ void launch_trimul(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgoing
     }
     {
         ProfScope ps(h, st, KC_TRIMUL_OUT);
-        if (!(h->pair_impl & 2))
-            launch_trimul_out_wl(h, st, w);
-        else
-            hipLaunchKernelGGL(k_trimul_out, dim3(h->B * N * ntile), dim3(256), 0, st, h->p, h->xcm, w.g_w, w.g_b, w.z_w, w.z_b,
-                           w.ln_in_g, w.ln_in_b, w.ln_out_g, w.ln_out_b, N, NP);
+        launch_trimul_out_wl(h, st, w);
     }
 }
 
 void launch_pair_transition(genie_ctx* h, hipStream_t st, const PairLayerW& w) {
     ProfScope ps(h, st, KC_PAIR_TRANSITION);
-    if (!(h->pair_impl & 4)) { launch_pair_transition_wl(h, st, w); return; }
-    const long long M = (long long)h->B * h->N * h->N;
-    const size_t lds = (2 * 64 * LDZ + 64) * sizeof(float);
-    hipLaunchKernelGGL(k_pair_transition, dim3((unsigned)((M + 63) / 64)), dim3(256), lds, st, h->p, h->rmaskf, w.pt_ln_g,
-                       w.pt_ln_b, w.pt_w1, w.pt_b1, w.pt_w2, w.pt_b2, h->N, M, h->d.pair_transition_n);
+    launch_pair_transition_wl(h, st, w);
 }
 
 void launch_ipa_bias(genie_ctx* h, hipStream_t st) {
@@ -622,8 +451,6 @@ void pair_kernels_init() {
     pair_wl_kernels_init();
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_trimul_contract<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         2 * 2 * 128 * LDK * sizeof(float));
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_transition), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (2 * 64 * LDZ + 64) * sizeof(float));
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_bias), hipFuncAttributeMaxDynamicSharedMemorySize,
                         128 * LDZ * sizeof(float));
 }
