@@ -40,53 +40,70 @@ __device__ __forceinline__ void load_tile64(float* tile, const float* __restrict
 }
 
 // ---------------------------------------------------------------------------
-// Triangle multiplication, contraction (trimul :57-82):
+// Triangle multiplication, contraction (triangular_multiplicative_update.py:57-82):
 //   x_cm[bc][i][j] = sum_k a_cm[bc][i][k] * b_cm[bc][j][k]   for bc = b*C + c.
 // WG tile (64*WT)^2, 4 waves of (32*WT)^2, K streamed in 32-wide chunks through
 // double-buffered LDS with register prefetch (one barrier per chunk).
+// PERSISTENT: a work-group walks tiles w = blockIdx.x, + gridDim.x, ... as one flat
+// (tile, chunk) sequence, so the first chunk of the next tile is already in flight while the
+// last chunk of the current one is multiplied and its result stored.
+// XCD-aware tile order: work-groups are dealt round-robin over the 8 XCDs, so ids with equal
+// id % 8 share an XCD; the T tiles of one (b, c) matrix take ids 8 apart and therefore share
+// each A / B panel through that XCD's L2 (placement affects speed only).
+// All global addressing is buffer + scalar offset (f32 MFMA and VALU share the FP32 lanes:
+// every vector instruction saved is MFMA time, see pair_wl_kernels.hip).
 // ---------------------------------------------------------------------------
 #define LDK 36
+typedef __amdgpu_buffer_rsrc_t crsrc_t;
 template <int WT>
-__global__ __launch_bounds__(256) void k_trimul_contract(const float* __restrict__ acm, const float* __restrict__ bcm,
-                                                         float* __restrict__ xcm, int NP, int n_mat) {
+__global__ __launch_bounds__(256, 2) void k_trimul_contract(const float* __restrict__ acm, const float* __restrict__ bcm,
+                                                            float* __restrict__ xcm, int NP, int n_mat, unsigned cm_bytes) {
     constexpr int TM = 64 * WT;
+    constexpr int NU = TM / 32;
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [2 buf][A|B][TM*LDK]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    // XCD-aware decode: work-groups are dealt round-robin over the 8 XCDs, so the T tiles of one
-    // (b, c) matrix take ids with equal id % 8 and sit 8 apart: they run on ONE XCD at about the
-    // same time and share each A / B panel through that XCD's L2 (placement affects speed only).
     const int tiles = (NP + TM - 1) / TM;
     const int T = tiles * tiles;
-    const int grp = blockIdx.x / (8 * T), rem = blockIdx.x % (8 * T);
-    const int tile = rem >> 3, mi = grp * 8 + (rem & 7);
-    if (mi >= n_mat) return;
-    const int i0 = (tile / tiles) * TM, j0 = (tile % tiles) * TM;
-    const size_t mat = (size_t)mi * NP * NP;
-    const float* A = acm + mat;
-    const float* Bm = bcm + mat;
-    const int lr = tid >> 3, c4 = tid & 7;
-    float4 ra[TM / 32], rb[TM / 32];
+    const int n_tiles = T * ((n_mat + 7) / 8) * 8;
     const int nk = NP / 32;
+    const crsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(acm), 0, cm_bytes, 0x00020000);
+    const crsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bcm), 0, cm_bytes, 0x00020000);
+    const crsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(xcm, 0, cm_bytes, 0x00020000);
+    const int lr = tid >> 3, c4 = tid & 7;
+    const int vload = (lr * NP + c4 * 4) * 4;          // per-lane byte offset inside a 32-row block of a panel
+    const int slds = lr * LDK + c4 * 4;
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    v4 rA[NU], rB[NU];
 
-    auto gload = [&](int kc) {
+    auto decode = [&](int w, int& mi, int& i0, int& j0) {       // tile id -> (matrix, tile origin)
+        const int grp = w / (8 * T), rem = w % (8 * T);
+        const int tile = rem >> 3;
+        mi = grp * 8 + (rem & 7);
+        i0 = (tile / tiles) * TM;
+        j0 = (tile % tiles) * TM;
+    };
+    auto gload = [&](int w, int kc) {
+        int mi, i0, j0;
+        decode(w, mi, i0, j0);
+        const int mclamp = min(mi, n_mat - 1);
+        const int mbase = mclamp * NP * NP * 4 + kc * 128;
 #pragma unroll
-        for (int u = 0; u < TM / 32; ++u) {
-            const int r = lr + 32 * u;
-            const float4 ta = *reinterpret_cast<const float4*>(A + (size_t)min(i0 + r, NP - 1) * NP + kc * 32 + c4 * 4);
-            const float4 tb = *reinterpret_cast<const float4*>(Bm + (size_t)min(j0 + r, NP - 1) * NP + kc * 32 + c4 * 4);
-            ra[u] = (i0 + r < NP) ? ta : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[u] = (j0 + r < NP) ? tb : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < NU; ++u) {
+            const int ia = min(i0 + 32 * u, NP - 32), jb = min(j0 + 32 * u, NP - 32);
+            rA[u] = __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(ra, vload, mbase + ia * NP * 4, 0));
+            rB[u] = __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(rb, vload, mbase + jb * NP * 4, 0));
+            if (i0 + 32 * u >= NP) rA[u] = v4{0.f, 0.f, 0.f, 0.f};
+            if (j0 + 32 * u >= NP) rB[u] = v4{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto swrite = [&](int buf) {
-        float* sa = sm + buf * 2 * TM * LDK;
-        float* sb = sa + TM * LDK;
+        float* sa = sm + buf * 2 * TM * LDK + slds;
 #pragma unroll
-        for (int u = 0; u < TM / 32; ++u) {
-            const int r = lr + 32 * u;
-            *reinterpret_cast<float4*>(sa + r * LDK + c4 * 4) = ra[u];
-            *reinterpret_cast<float4*>(sb + r * LDK + c4 * 4) = rb[u];
+        for (int u = 0; u < NU; ++u) {
+            *reinterpret_cast<v4*>(sa + 32 * u * LDK) = rA[u];
+            *reinterpret_cast<v4*>(sa + TM * LDK + 32 * u * LDK) = rB[u];
         }
     };
 
@@ -96,12 +113,20 @@ __global__ __launch_bounds__(256) void k_trimul_contract(const float* __restrict
 #pragma unroll
         for (int n = 0; n < WT; ++n) acc[m][n] = zero16();
 
-    gload(0);
+    int w = blockIdx.x;
+    if (w >= n_tiles) return;
+    const int my_tiles = (n_tiles - 1 - w) / gridDim.x + 1;
+    const int total = my_tiles * nk;
+    gload(w, 0);
     swrite(0);
     __syncthreads();
-    for (int kc = 0; kc < nk; ++kc) {
-        if (kc + 1 < nk) gload(kc + 1);
-        const float* sa = sm + (kc & 1) * 2 * TM * LDK;
+    int kc = 0;
+    for (int it = 0; it < total; ++it) {
+        const bool last_chunk = kc == nk - 1;
+        const int wn_next = last_chunk ? w + gridDim.x : w;
+        const int kc_next = last_chunk ? 0 : kc + 1;
+        if (it + 1 < total) gload(wn_next, kc_next);
+        const float* sa = sm + (it & 1) * 2 * TM * LDK;
         const float* sb = sa + TM * LDK;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
@@ -115,21 +140,34 @@ __global__ __launch_bounds__(256) void k_trimul_contract(const float* __restrict
 #pragma unroll
                 for (int n = 0; n < WT; ++n) acc[m][n] = mfma_8k(af[m], bf[n], acc[m][n]);
         }
-        if (kc + 1 < nk) swrite((kc + 1) & 1);
-        __syncthreads();
-    }
-    float* X = xcm + mat;
+        if (last_chunk) {       // store the finished tile (row = acc_row(r): 4 (lane>>5) in voffset, the rest scalar)
+            int mi, i0, j0;
+            decode(w, mi, i0, j0);
+            if (mi < n_mat) {
+                const int vst = ((4 * (lane >> 5)) * NP + (lane & 31)) * 4;
 #pragma unroll
-    for (int m = 0; m < WT; ++m)
+                for (int m = 0; m < WT; ++m)
 #pragma unroll
-        for (int n = 0; n < WT; ++n) {
-            const int j = j0 + (wn * WT + n) * 32 + (lane & 31);
+                    for (int n = 0; n < WT; ++n) {
+                        const int ib = i0 + (wm * WT + m) * 32, jb = j0 + (wn * WT + n) * 32;
+                        if (ib < NP && jb < NP) {
+                            const int sbase = ((mi * NP + ib) * NP + jb) * 4;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = i0 + (wm * WT + m) * 32 + acc_row(r, lane);
-                if (i < NP && j < NP) X[(size_t)i * NP + j] = acc[m][n][r];
+                            for (int r = 0; r < 16; ++r) {
+                                const float v = acc[m][n][r];     // (bit_cast straight from a vector element picks element 0)
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rx, vst,
+                                                                      sbase + ((r & 3) + 8 * (r >> 2)) * NP * 4, 0);
+                            }
+                        }
+                        acc[m][n] = zero16();
+                    }
             }
         }
+        if (it + 1 < total) swrite((it + 1) & 1);
+        __syncthreads();
+        w = wn_next;
+        kc = kc_next;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -413,16 +451,21 @@ void launch_trimul(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgoing
     {
         ProfScope ps(h, st, KC_TRIMUL_CONTRACT);
         const int BC = h->B * h->d.c_hidden_mul;
+        const unsigned cm_bytes = (unsigned)((size_t)BC * NP * NP * 4);
+        static int num_cu = 0;
+        if (!num_cu) { int dev = 0; hipDeviceProp_t pr; (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&pr, dev); num_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
         if (NP >= 128) {
             const int tiles = (NP + 127) / 128;
+            const int n_tiles = tiles * tiles * ((BC + 7) / 8) * 8;
             const size_t lds = 2 * 2 * 128 * LDK * sizeof(float);
-            hipLaunchKernelGGL(k_trimul_contract<2>, dim3(tiles * tiles * ((BC + 7) / 8) * 8), dim3(256), lds, st, h->acm, h->bcm,
-                               h->xcm, NP, BC);
+            hipLaunchKernelGGL(k_trimul_contract<2>, dim3(n_tiles < 2 * num_cu ? n_tiles : 2 * num_cu), dim3(256), lds, st, h->acm,
+                               h->bcm, h->xcm, NP, BC, cm_bytes);
         } else {
             const int tiles = (NP + 63) / 64;
+            const int n_tiles = tiles * tiles * ((BC + 7) / 8) * 8;
             const size_t lds = 2 * 2 * 64 * LDK * sizeof(float);
-            hipLaunchKernelGGL(k_trimul_contract<1>, dim3(tiles * tiles * ((BC + 7) / 8) * 8), dim3(256), lds, st, h->acm, h->bcm,
-                               h->xcm, NP, BC);
+            hipLaunchKernelGGL(k_trimul_contract<1>, dim3(n_tiles < 4 * num_cu ? n_tiles : 4 * num_cu), dim3(256), lds, st, h->acm,
+                               h->bcm, h->xcm, NP, BC, cm_bytes);
         }
     }
     {
