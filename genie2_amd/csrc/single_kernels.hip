@@ -428,28 +428,36 @@ __global__ __launch_bounds__(256) void k_ipa_attn_t(const float* __restrict__ pr
     }
     __syncthreads();
     float* crow = cat + (size_t)row * NCAT;
-    // o and o_pt: 480 outputs, 2 per thread, j unrolled x8 (weights: two ds_read_b128, values: 8 loads in flight)
+    // o and o_pt: 480 outputs, 2 per thread handled together, j unrolled x8 (weights: ds_read_b128 pairs,
+    // values: 16 independent L2 loads in flight per step)
+    {
+        const int u0 = tid, u1 = tid + 256;
+        const bool has1 = u1 < HC + NPT;
+        const bool o0 = u0 < HC, o1 = u1 < HC;                       // u1 >= 256 > HC for the base shape, kept general
+        const int w0 = o0 ? u0 : u0 - HC, w1 = has1 ? (o1 ? u1 : u1 - HC) : 0;
+        const float* ar0 = att + (o0 ? (u0 / C) : (w0 / (PV * 3))) * NP8;
+        const float* ar1 = att + (o1 ? (u1 / C) : (w1 / (PV * 3))) * NP8;
+        const float* vv0 = o0 ? v + (size_t)b * N * HC + u0 : vp + (size_t)b * N * NPT + w0;
+        const float* vv1 = o1 ? v + (size_t)b * N * HC + u1 : vp + (size_t)b * N * NPT + w1;
+        const int ld0 = o0 ? HC : NPT, ld1 = o1 ? HC : NPT;
+        float acc0 = 0.f, acc1 = 0.f;
+        for (int j0 = 0; j0 < NP8; j0 += 8) {
+            float x0[8], x1[8];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int u = tid + 256 * half;
-        if (u < HC + NPT) {
-            const bool is_o = u < HC;
-            const int w = is_o ? u : u - HC;
-            const float* ar = att + (is_o ? (u / C) : (w / (PV * 3))) * NP8;
-            const float* vv = is_o ? v + (size_t)b * N * HC + u : vp + (size_t)b * N * NPT + w;
-            const int ld = is_o ? HC : NPT;
-            float acc = 0.f;
-            for (int j0 = 0; j0 < NP8; j0 += 8) {
-                float xv[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) xv[k] = vv[(size_t)min(j0 + k, N - 1) * ld];
-                const float4 a0 = *reinterpret_cast<const float4*>(ar + j0);
-                const float4 a1 = *reinterpret_cast<const float4*>(ar + j0 + 4);
-                acc += a0.x * xv[0]; acc += a0.y * xv[1]; acc += a0.z * xv[2]; acc += a0.w * xv[3];
-                acc += a1.x * xv[4]; acc += a1.y * xv[5]; acc += a1.z * xv[6]; acc += a1.w * xv[7];
+            for (int k = 0; k < 8; ++k) {
+                const int jc = min(j0 + k, N - 1);
+                x0[k] = vv0[(size_t)jc * ld0];
+                x1[k] = vv1[(size_t)jc * ld1];
             }
-            if (is_o) crow[u] = acc; else opt[w] = acc;
+            const float4 a0 = *reinterpret_cast<const float4*>(ar0 + j0), a1 = *reinterpret_cast<const float4*>(ar0 + j0 + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(ar1 + j0), b1 = *reinterpret_cast<const float4*>(ar1 + j0 + 4);
+            acc0 += a0.x * x0[0]; acc0 += a0.y * x0[1]; acc0 += a0.z * x0[2]; acc0 += a0.w * x0[3];
+            acc0 += a1.x * x0[4]; acc0 += a1.y * x0[5]; acc0 += a1.z * x0[6]; acc0 += a1.w * x0[7];
+            acc1 += b0.x * x1[0]; acc1 += b0.y * x1[1]; acc1 += b0.z * x1[2]; acc1 += b0.w * x1[3];
+            acc1 += b1.x * x1[4]; acc1 += b1.y * x1[5]; acc1 += b1.z * x1[6]; acc1 += b1.w * x1[7];
         }
+        if (o0) crow[u0] = acc0; else opt[w0] = acc0;
+        if (has1) { if (o1) crow[u1] = acc1; else opt[w1] = acc1; }
     }
     // o_pair: thread = (channel quad c4, j-group jg of 8); the p row is streamed once
     {
@@ -458,12 +466,12 @@ __global__ __launch_bounds__(256) void k_ipa_attn_t(const float* __restrict__ pr
 #pragma unroll
         for (int hh = 0; hh < H; ++hh) acc[hh] = make_float4(0.f, 0.f, 0.f, 0.f);
         const float* zr = z + ((size_t)row * N) * CP + c4 * 4;
-        for (int j0 = jg; j0 < N; j0 += 32) {        // 4 rows (j0, j0+8, j0+16, j0+24) in flight
-            float4 zz[4];
+        for (int j0 = jg; j0 < N; j0 += 64) {        // 8 rows (j0, j0+8, ..., j0+56) in flight
+            float4 zz[8];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) zz[k] = *reinterpret_cast<const float4*>(zr + (size_t)min(j0 + 8 * k, N - 1) * CP);
+            for (int k = 0; k < 8; ++k) zz[k] = *reinterpret_cast<const float4*>(zr + (size_t)min(j0 + 8 * k, N - 1) * CP);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 8; ++k) {
                 const int j = j0 + 8 * k;
                 if (j < N) {
 #pragma unroll
