@@ -217,7 +217,9 @@ __global__ __launch_bounds__(256, 2) void k_trimul_proj_wl(const float* __restri
 #pragma unroll
             for (int kb = 0; kb < 16; ++kb) {
                 const v4f np = sfrag(stage, min(2 * kb + 2, 30), lane), ng = sfrag(stage, min(2 * kb + 3, 31), lane);
+                PIPE_FENCE();
                 mfma_a2(fp, fg, zf[kb], ap, ag);
+                PIPE_FENCE();
                 fp = np; fg = ng;
             }
             stage_landed();
@@ -273,8 +275,6 @@ __global__ __launch_bounds__(256, 2) void k_pair_transition_wl(float* __restrict
     int tile = blockIdx.x;
     issue(0, 0);
     for (int u = threadIdx.x; u < n_hb * 32; u += 256) sb1[u] = b1[u];
-    float4 raw[16];
-    load_raw_tile(raw, row_ptr(tile), h);
     const float c0 = b2[pl], c1 = b2[32 + pl], c2 = b2[64 + pl], c3 = b2[96 + pl];
     __syncthreads();
 #pragma unroll 1
@@ -291,8 +291,9 @@ __global__ __launch_bounds__(256, 2) void k_pair_transition_wl(float* __restrict
             const int rem = (int)(idx - (long long)bb * N * N);
             m_own = rmask[bb * N + rem / N] * rmask[bb * N + rem % N];
         }
-        float4 zn[16];
-        norm_from_raw(zn, raw);
+        float4 zn[16];          // (2048 MFMAs per tile: the row load is not worth 64 prefetch registers here)
+        load_raw_tile(zn, row_ptr(tile), h);
+        norm_from_raw(zn, zn);
         f32x16 o0, o1, o2, o3;
         {
             float e0 = c0, e1 = c1, e2 = c2, e3 = c3;
@@ -304,7 +305,6 @@ __global__ __launch_bounds__(256, 2) void k_pair_transition_wl(float* __restrict
         for (int hb = 0; hb < n_hb; ++hb) {
             if (hb + 1 < n_hb) issue(hb + 1, (hb + 1) & 1);
             else if (more) issue(0, 0);
-            if (hb == n_hb / 2 && more) load_raw_tile(raw, row_ptr(tile + gridDim.x), h);
             const float* stage = sm + (hb & 1) * STAGE_FLOATS;
             f32x16 d, d2 = zero16();              // two partial sums over alternate k-blocks; d starts at the bias
 #pragma unroll
@@ -313,8 +313,10 @@ __global__ __launch_bounds__(256, 2) void k_pair_transition_wl(float* __restrict
 #pragma unroll
             for (int u = 0; u < 16; u += 2) {
                 const v4f n0 = sfrag(stage, min(u + 2, 14), lane), n1 = sfrag(stage, min(u + 3, 15), lane);
+                PIPE_FENCE();
                 MF1(f0.x, zn[u].x, d); MF1(f1.x, zn[u + 1].x, d2); MF1(f0.y, zn[u].y, d); MF1(f1.y, zn[u + 1].y, d2);
                 MF1(f0.z, zn[u].z, d); MF1(f1.z, zn[u + 1].z, d2); MF1(f0.w, zn[u].w, d); MF1(f1.w, zn[u + 1].w, d2);
+                PIPE_FENCE();
                 f0 = n0; f1 = n1;
             }
             v4f w0 = sfrag(stage, 16, lane), w1f = sfrag(stage, 20, lane), w2f = sfrag(stage, 24, lane), w3 = sfrag(stage, 28, lane);
@@ -326,7 +328,9 @@ __global__ __launch_bounds__(256, 2) void k_pair_transition_wl(float* __restrict
                 const int qn = min(q + 1, 3);
                 const v4f n0 = sfrag(stage, 16 + qn, lane), n1 = sfrag(stage, 20 + qn, lane), n2 = sfrag(stage, 24 + qn, lane),
                           n3 = sfrag(stage, 28 + qn, lane);
+                PIPE_FENCE();
                 mfma_b4(hf, w0, w1f, w2f, w3, o0, o1, o2, o3);
+                PIPE_FENCE();
                 w0 = n0; w1f = n1; w2f = n2; w3 = n3;
             }
             __syncthreads();
@@ -430,7 +434,9 @@ __global__ __launch_bounds__(256, 2) void k_trimul_out_wl(float* __restrict__ z,
 #pragma unroll
                 for (int kb = 0; kb < 16; ++kb) {
                     const v4f n0 = sfrag(stage, min(kb + 1, 15), lane), n1 = sfrag(stage, 16 + min(kb + 1, 15), lane);
+                    PIPE_FENCE();
                     mfma_b2(zf[kb], f0, f1, ga, gb);
+                    PIPE_FENCE();
                     f0 = n0; f1 = n1;
                 }
 #pragma unroll
@@ -455,7 +461,9 @@ __global__ __launch_bounds__(256, 2) void k_trimul_out_wl(float* __restrict__ z,
 #pragma unroll
                 for (int kb = 0; kb < 16; ++kb) {
                     const v4f n0 = sfrag(stage, min(kb + 1, 15), lane), n1 = sfrag(stage, 16 + min(kb + 1, 15), lane);
+                    PIPE_FENCE();
                     mfma_b2(xf[kb], f0, f1, a0, a1);
+                    PIPE_FENCE();
                     f0 = n0; f1 = n1;
                 }
                 stage_landed();
