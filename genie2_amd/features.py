@@ -115,3 +115,51 @@ def save_np_features_to_pdb(np_features, filepath):
         lines.append(''.join(cols[:80]) + '\n')
     with open(filepath, 'w') as fh:
         fh.writelines(lines)
+
+
+RESTYPE_ORDER = {c: i for i, c in enumerate(RESTYPES)}
+_RESTYPE_3_TO_1 = {t: RESTYPES[i] for i, t in enumerate(RESTYPE_3)}
+
+
+def parse_pdb(filepath):
+    """feat_utils.py:377-416: per-chain residue-type indices and C-alpha coordinates."""
+    import gzip
+    seqs, coords, current = [], [], None
+    opener = (lambda p: gzip.open(p, 'rt')) if filepath.endswith('.gz') else (lambda p: open(p, 'r'))
+    with opener(filepath) as fh:
+        for line in fh:
+            if line.startswith('ATOM') and line[13:15].strip() == 'CA':
+                chain = line[21]
+                if current is None or chain != current:
+                    seqs.append([])
+                    coords.append([])
+                    current = chain
+                seqs[-1].append(RESTYPE_ORDER[_RESTYPE_3_TO_1[line[17:20]]])
+                coords[-1].append([float(line[30:38]), float(line[38:46]), float(line[46:54])])
+    return seqs, coords
+
+
+def create_np_features_from_pdb(filepath):
+    """feat_utils.py:66-93: unconditional features of a structure file (coordinates centred)."""
+    seqs, coords = parse_pdb(filepath)
+    f = create_empty_np_features([len(s) for s in seqs])
+    xyz = np.concatenate(coords)
+    f['aatype'] = np.eye(20)[np.concatenate(seqs)].astype(int)
+    f['atom_positions'] = (xyz - np.mean(xyz, axis=0, keepdims=True)).astype(float)
+    return f
+
+
+def create_np_features_from_motif_pdb(filepath):
+    """feat_utils.py:95-130: sample a scaffold/motif arrangement satisfying the problem file and
+    place the motif's residue types and C-alpha coordinates at the motif positions."""
+    from .motif import load_motif_spec, sample_motif_mask
+    spec = load_motif_spec(filepath)
+    seqs, coords = parse_pdb(filepath)
+    mask = sample_motif_mask(spec)
+    f = create_empty_np_features([len(mask['sequence'])])
+    f['aatype'][mask['sequence']] = np.eye(20)[np.concatenate(seqs)]
+    f['atom_positions'][mask['sequence']] = np.concatenate(coords)
+    f['fixed_sequence_mask'] = mask['sequence']
+    f['fixed_structure_mask'] = mask['structure']
+    f['fixed_group'] = mask['group']
+    return f

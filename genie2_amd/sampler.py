@@ -88,3 +88,27 @@ class UnconditionalSampler(BaseSampler):
         for i, np_features in enumerate(list_np_features):
             name = '{}_{}'.format(params['prefix'], params['offset'] + i)
             F.save_np_features_to_pdb(np_features, os.path.join(params['outdir'], 'pdbs', name + '.pdb'))
+
+
+class ScaffoldSampler(BaseSampler):
+    """genie/sampler/scaffold.py:12-169: motif scaffolding.  Conditioning enters only through
+    the features (aatype, atom_positions, fixed_* masks); scaffold lengths are drawn per sample,
+    so batches are ragged and the residue mask matters."""
+
+    def setup(self):
+        self.add_required_parameter('filepath')
+
+    def on_sample_start(self, params):
+        for sub in ('pdbs', 'motif_pdbs'):
+            os.makedirs(os.path.join(params['outdir'], sub), exist_ok=True)
+
+    def create_np_features(self, params):
+        return F.create_np_features_from_motif_pdb(params['filepath'])
+
+    def on_sample_end(self, params, list_np_features):
+        from .motif import save_motif_pdb
+        for i, np_features in enumerate(list_np_features):
+            name = '{}_{}'.format(params['prefix'], params['offset'] + i)
+            F.save_np_features_to_pdb(np_features, os.path.join(params['outdir'], 'pdbs', name + '.pdb'))
+            save_motif_pdb(params['filepath'], np_features['fixed_sequence_mask'],
+                           os.path.join(params['outdir'], 'motif_pdbs', name + '.pdb'))

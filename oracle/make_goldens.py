@@ -334,6 +334,76 @@ def gen_trajectory(sd):
          scale=scale, seed=seed, ref_steps_per_s=Tn / dt, ref_threads=torch.get_num_threads())
 
 
+def gen_motif(sd):
+    """Config 4 (scaffold path): the reference's motif-problem parser, mask sampler, feature
+    builder and motif-PDB writer on tests/golden/motif_problem_6E6R.pdb (REMARK 999 header
+    authored for the tests; ATOM records = the reference's 6E6R_long_motif.pdb data file), and a
+    ragged, motif-conditioned B=2 trajectory through its real ScaffoldSampler._sample."""
+    from genie.utils import motif_utils
+    from genie.sampler.scaffold import ScaffoldSampler
+    import genie.sampler.base as ref_base
+    path = os.path.join(OUT, 'motif_problem_6E6R.pdb')
+    spec = motif_utils.load_motif_spec(path)
+    out = dict(spec_name=spec['name'], spec_min=spec['min_total_length'], spec_max=spec['max_total_length'],
+               spec_structures=np.array([[s['type'] == 'motif', s.get('min_length', s.get('start_index')),
+                                          s.get('max_length', s.get('end_index')),
+                                          ord(s.get('group', ' ')), ord(s.get('chain', ' '))]
+                                         for s in spec['structures']]))
+    seqs, coords = feat_utils.parse_pdb(path)
+    out['parse_seq'] = np.array(seqs[0]); out['parse_coords'] = np.array(coords[0])
+    for seed in range(4):
+        np.random.seed(seed)
+        f = feat_utils.create_np_features_from_motif_pdb(path)
+        for k, v in f.items():
+            out[f'seed{seed}_{k}'] = np.asarray(v)
+        with tempfile.TemporaryDirectory() as d:
+            motif_utils.save_motif_pdb(path, f['fixed_sequence_mask'], os.path.join(d, 'm.pdb'))
+            out[f'seed{seed}_motif_pdb'] = np.frombuffer(open(os.path.join(d, 'm.pdb'), 'rb').read(), dtype=np.uint8)
+    # unconditional features of the same file (feat_utils.create_np_features_from_pdb)
+    f = feat_utils.create_np_features_from_pdb(path)
+    for k, v in f.items():
+        out[f'frompdb_{k}'] = np.asarray(v)
+    save('motif_features', **out)
+
+    Tn, B, scale, seed = 20, 2, 0.6, 7
+    cfg = ref_config(Tn)
+    model = ref_denoiser(cfg, sd)
+    sampler = ScaffoldSampler(_Shim(cfg, model))
+    np.random.seed(seed)
+    lens = [len(feat_utils.create_np_features_from_motif_pdb(path)['residue_mask']) for _ in range(B)]
+    N = max(lens)
+    torch.manual_seed(seed)
+    noise = torch.stack([torch.randn(B, N, 3) for _ in range(Tn)])
+    rec, traj = [], []
+    orig_q = ref_pfn.rot_to_quat
+    ref_pfn.rot_to_quat = lambda r: (lambda q: (rec.append(O.quat_sign_codes(q)), q)[1])(orig_q(r))
+    orig_f = ref_base.compute_frenet_frames
+    ref_base.compute_frenet_frames = lambda c, ch, m: (traj.append(c.clone()) or orig_f(c, ch, m))
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    try:
+        res = sampler._sample(dict(filepath=path, scale=scale, strength=0, num_samples=B, outdir='.', prefix='x', offset=0))
+    finally:
+        ref_pfn.rot_to_quat = orig_q
+        ref_base.compute_frenet_frames = orig_f
+    assert [len(r['residue_mask']) for r in res] == lens and torch.equal(traj[0], noise[0])
+    final = torch.zeros(B, N, 3)
+    for b, r in enumerate(res):
+        final[b, :lens[b]] = torch.tensor(r['atom_positions'], dtype=torch.float32)
+    codes = torch.stack(rec)
+    # restatement check: same features (np seed), recorded signs
+    np.random.seed(seed)
+    feats = feat_utils.convert_np_features_to_tensor(feat_utils.batchify_np_features(
+        [feat_utils.create_np_features_from_motif_pdb(path) for _ in range(B)]), 'cpu')
+    dims = dict(O.BASE_DIMS, n_timestep=Tn)
+    mine, _, _ = O.sample_loop(sd, dims, feats, noise, scale, 'closed', codes)
+    rms = float(final.pow(2).mean().sqrt())
+    print(f'  scaffold: lengths {lens}; oracle(closed+codes) vs reference max|dCa| {maxdiff(mine, final):.2e} (RMS {rms:.2f})')
+    assert maxdiff(mine, final) <= 1e-4 * max(rms, 1.0)
+    save('trajectory_scaffold_t20', noise=noise, quat_codes=codes, final=final, lengths=np.array(lens),
+         scale=scale, seed=seed, **feats_to_np(feats))
+
+
 def main():
     torch.manual_seed(0)
     print('weights (synthetic recipe, seed 0)')
@@ -349,12 +419,16 @@ def main():
          n_params=sum(v.numel() for v in sd.values()),
          keys=np.array(list(ref_sd.keys())), shapes=np.array([str(tuple(v.shape)) for v in ref_sd.values()]),
          probe=sd['structure_net.net.7.ipa.linear_out.weight'][:4, :8])
+    if len(sys.argv) > 1 and sys.argv[1] == 'motif':
+        print('motif'); gen_motif(sd)
+        return
     print('schedule'); gen_schedule()
     print('encoding'); gen_encoding()
     print('geometry'); gen_geometry()
     print('pdb'); gen_pdb()
     gen_single_calls(sd)
     print('trajectory'); gen_trajectory(sd)
+    print('motif'); gen_motif(sd)
 
 
 if __name__ == '__main__':
