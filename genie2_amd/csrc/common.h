@@ -153,16 +153,26 @@ enum KernelClass {
     KC_IPA_BIAS, KC_IPA_PREP, KC_IPA_ATTN, KC_BB_UPDATE, KC_P_SAMPLE, KC_MISC, KC_COUNT
 };
 
+// "hx" images (hx.h): weights split in f16 halves, in stage order, + the scales that go with them
+struct HxTransW { const unsigned char* img; float *b1s, *b2s; float sx, c1, c2; };
+
+struct HxTriW {
+    const unsigned char *img_proj, *img_out;   // 8 stages (passes) / 4 stages (W_g{0,1}, W_z{0,1}, W_g{2,3}, W_z{2,3})
+    float *bias_proj, *bgs, *bzs;              // scaled biases (initial accumulators)
+    float sx, cpa, cpb, cg, cx, cgo, cz;       // operand scale / epilogue rescales
+};
 struct TriMulW {
     float *proj_w;            // packed [512][128]: a_p | b_p | a_g | b_g
     float *proj_b;            // [512] same order
     float *g_w, *g_b;         // packed [128][128], [128]
     float *z_w, *z_b;         // packed [c_p][c_hidden]
     float *ln_in_g, *ln_in_b, *ln_out_g, *ln_out_b;
+    HxTriW hx;
 };
 struct PairLayerW {
     TriMulW out, in;
     float *pt_ln_g, *pt_ln_b, *pt_w1, *pt_b1, *pt_w2, *pt_b2;   // w1 packed [512][128], w2 packed [128][512]
+    HxTransW hx_pt;
 };
 struct StructLayerW {
     float *proj_w, *proj_b;       // packed [1152][384]: q | kv | q_pts | kv_pts
@@ -182,6 +192,8 @@ struct genie_ctx {
     // weights
     bool have_weights;
     float* wdev;                  // one device allocation holding everything below
+    bool hx;                      // pair-stack GEMMs in split-f16 arithmetic (hx.h); GENIE_MATH=f32 selects the f32-MFMA kernels
+    unsigned char* hxdev;         // device allocation of the hx weight images
     size_t wdev_floats;
     float *single_w;              // packed [384][856]
     float *pij_w;                 // packed [256][384]: linear_s_p_i | linear_s_p_j

@@ -3,6 +3,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
+#include <algorithm>
+#include <cmath>
 #include <new>
 #include <string>
 #include <vector>
@@ -96,6 +99,10 @@ int genie_create(const genie_dims_t* dims, int device, genie_handle_t* out) {
     h->pair = new PairLayerW[dims->n_pair_transform_layer > 0 ? dims->n_pair_transform_layer : 1]();
     h->st = new StructLayerW[dims->n_structure_layer]();
     pair_kernels_init();
+    {   // GENIE_MATH=f32: exact-f32 MFMA kernels; default: split-f16 ("hx", same accuracy class, see hx.h)
+        const char* m = getenv("GENIE_MATH");
+        h->hx = m && !strcmp(m, "hx");
+    }
     *out = h;
     return GENIE_OK;
 }
@@ -110,6 +117,7 @@ void genie_destroy(genie_handle_t h) {
     hipSetDevice(h->device);
     free_batch(h);
     if (h->wdev) hipFree(h->wdev);
+    if (h->hxdev) hipFree(h->hxdev);
     if (h->pos_tab) hipFree(h->pos_tab);
     free(h->sched_host);
     for (int i = 0; i < h->prof_n; ++i) { hipEventDestroy(h->prof_recs[i].a); hipEventDestroy(h->prof_recs[i].b); }
@@ -148,6 +156,57 @@ struct Img {
         return o;
     }
 };
+// ---- "hx" images (hx.h): f16 hi/lo halves in MFMA fragment order, units in consumption order ----
+uint16_t f2h(float f) {                 // f32 -> f16, round to nearest even, subnormals kept
+    uint32_t x; memcpy(&x, &f, 4);
+    const uint16_t sign = (uint16_t)((x >> 16) & 0x8000);
+    x &= 0x7FFFFFFFu;
+    if (x >= 0x7F800000u) return (uint16_t)(sign | (x > 0x7F800000u ? 0x7E00 : 0x7C00));
+    if (x >= 0x477FF000u) return (uint16_t)(sign | 0x7C00);           // >= 65520 rounds to infinity
+    if (x < 0x38800000u) {                                            // below 2^-14: subnormal half = round(|f| 2^24)
+        float a; memcpy(&a, &x, 4);
+        return (uint16_t)(sign | (uint16_t)nearbyintf(a * 16777216.0f));
+    }
+    const uint32_t mant = x & 0x7FFFFFu, rem = mant & 0x1FFFu;
+    uint32_t r = (((x >> 23) - 112u) << 10) | (mant >> 13);
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;           // a carry runs into the exponent as it should
+    return (uint16_t)(sign | r);
+}
+float h2f(uint16_t v) {
+    const int e = (v >> 10) & 31, m = v & 1023;
+    float r = e == 0 ? ldexpf((float)m, -24) : e == 31 ? (m ? NAN : INFINITY) : ldexpf((float)(1024 + m), e - 25);
+    return (v & 0x8000) ? -r : r;
+}
+float p2floor(double x) { return (x > 0 && std::isfinite(x)) ? (float)ldexp(1.0, (int)floor(log2(x))) : 1.0f; }
+struct HxImg {
+    std::vector<uint16_t> d;
+    size_t begin() { d.resize((d.size() + 127) & ~(size_t)127); return d.size() * 2; }       // 256-B aligned byte offset
+    // one unit: get(idx = lane & 31, half-wave h, e) -> scaled f32 value of slot (lane, e)
+    template <class F> void unit(F get) {
+        const size_t o = d.size();
+        d.resize(o + 1024);
+        for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 8; ++e) {
+                const float v = get(lane & 31, lane >> 5, e);
+                const uint16_t hi = f2h(v);
+                d[o + lane * 8 + e] = hi;
+                d[o + 512 + lane * 8 + e] = f2h(v - h2f(hi));
+            }
+    }
+};
+double max_abs(const float* w, size_t n) { double m = 0; for (size_t i = 0; i < n; ++i) m = std::max(m, (double)fabsf(w[i])); return m; }
+// Cauchy-Schwarz bound of |W xhat + b| over LayerNorm outputs (|xhat|_2 <= sqrt(cols))
+double hx_bound(const float* W, const float* b, int rows, int cols) {
+    double m = 0;
+    for (int r = 0; r < rows; ++r) {
+        double ss = 0;
+        for (int k = 0; k < cols; ++k) ss += (double)W[(size_t)r * cols + k] * W[(size_t)r * cols + k];
+        m = std::max(m, sqrt(ss * cols) + fabs((double)b[r]));
+    }
+    return m;
+}
+constexpr float HX_SX = 1024.0f;        // LayerNorm outputs: |xhat| <= sqrt(128) -> < 11586 after scaling
+
 struct Cur {
     const float* p; size_t left;
     const float* take(size_t n) { if (n > left) { left = 0; return nullptr; } const float* r = p; p += n; left -= n; return r; }
@@ -180,7 +239,9 @@ int genie_load_weights(genie_handle_t h, const float* blob, size_t n_floats) {
     const size_t cs = d.c_s, cp = d.c_p, ch = d.c_hidden_mul;
     Cur c{blob, n_floats};
     Img img;
+    HxImg hx;
     std::vector<std::pair<float**, size_t>> fix;     // (pointer slot, offset)
+    std::vector<std::pair<const unsigned char**, size_t>> hxfix;
     auto slot = [&](float** s, size_t off) { fix.push_back({s, off}); };
 
     size_t ones_off, zeros_off;
@@ -247,6 +308,35 @@ int genie_load_weights(genie_handle_t h, const float* blob, size_t n_floats) {
             slot(&T.proj_b, img.raw(bb.data(), bb.size()));
             slot(&T.g_w, img.pack(gw.data(), (int)cp, (int)cp)); slot(&T.g_b, img.raw(gb.data(), cp));
             slot(&T.z_w, img.pack(zw.data(), (int)cp, (int)ch)); slot(&T.z_b, img.raw(zb.data(), cp));
+            {   // hx images (hx.h).  a / b are bounded by their projection rows (the gate is in (0, 1)).
+                HxTriW& X = T.hx;
+                const float sp = p2floor(16384.0 / max_abs(w.data(), 2 * ch * cp)), sg = p2floor(16384.0 / max_abs(w.data() + 2 * ch * cp, 2 * ch * cp));
+                const float sa = p2floor(32768.0 / hx_bound(w.data(), bb.data(), (int)ch, (int)cp));
+                const float sb = p2floor(32768.0 / hx_bound(w.data() + ch * cp, bb.data() + ch, (int)ch, (int)cp));
+                const float sgo = p2floor(16384.0 / max_abs(gw.data(), cp * cp)), szo = p2floor(16384.0 / max_abs(zw.data(), cp * ch));
+                X.sx = HX_SX; X.cpa = sa / (HX_SX * sp); X.cpb = sb / (HX_SX * sp); X.cg = 1.0f / (HX_SX * sg); X.cx = 1.0f / (sa * sb);
+                X.cgo = 1.0f / (HX_SX * sgo); X.cz = 1.0f / (HX_SX * szo);
+                hxfix.push_back({&X.img_proj, hx.begin()});
+                for (size_t pass = 0; pass < 8; ++pass)
+                    for (int kc = 0; kc < 8; ++kc) {
+                        hx.unit([&](int i, int hh, int e) { return w[(32 * pass + i) * cp + 16 * kc + 8 * hh + e] * sp; });
+                        hx.unit([&](int i, int hh, int e) { return w[(2 * ch + 32 * pass + i) * cp + 16 * kc + 8 * hh + e] * sg; });
+                    }
+                hxfix.push_back({&X.img_out, hx.begin()});
+                for (int st = 0; st < 4; ++st)
+                    for (int obl = 0; obl < 2; ++obl)
+                        for (int kc = 0; kc < 8; ++kc) {
+                            const std::vector<float>& m = (st & 1) ? zw : gw;
+                            const float sc = (st & 1) ? szo : sgo;
+                            const size_t ob = 2 * (st >> 1) + obl;
+                            hx.unit([&](int j, int hh, int e) { return m[(32 * ob + j) * cp + 16 * kc + 8 * hh + e] * sc; });
+                        }
+                std::vector<float> bp(4 * ch), bgs(cp), bzs(cp);
+                for (size_t r = 0; r < 4 * ch; ++r) bp[r] = bb[r] * HX_SX * (r < 2 * ch ? sp : sg);
+                for (size_t r = 0; r < cp; ++r) { bgs[r] = gb[r] * HX_SX * sgo; bzs[r] = zb[r] * HX_SX * szo; }
+                slot(&X.bias_proj, img.raw(bp.data(), bp.size()));
+                slot(&X.bgs, img.raw(bgs.data(), cp)); slot(&X.bzs, img.raw(bzs.data(), cp));
+            }
             // the affine now lives in the weights: kernels that still take gamma / beta get (1, 0)
             slot(&T.ln_in_g, ones_off); slot(&T.ln_in_b, zeros_off);
             slot(&T.ln_out_g, ones_off); slot(&T.ln_out_b, zeros_off);
@@ -260,6 +350,24 @@ int genie_load_weights(genie_handle_t h, const float* blob, size_t n_floats) {
             fold_ln(w1v, b1v, (int)nh, (int)cp, lg, lb);
             slot(&L.pt_ln_g, ones_off); slot(&L.pt_ln_b, zeros_off);
             slot(&L.pt_w1, img.pack(w1v.data(), (int)nh, (int)cp)); slot(&L.pt_b1, img.raw(b1v.data(), nh));
+            // hx image: per hidden block of 32, 8 units of W1 (k-chunks) then 8 of W2 (chunk c, output block ob)
+            HxTransW& X = L.hx_pt;
+            const float s1 = p2floor(16384.0 / max_abs(w1v.data(), nh * cp)), s2 = p2floor(16384.0 / max_abs(w2, cp * nh));
+            const float sh = p2floor(32768.0 / hx_bound(w1v.data(), b1v.data(), (int)nh, (int)cp));
+            X.sx = HX_SX; X.c1 = sh / (HX_SX * s1); X.c2 = 1.0f / (sh * s2);
+            hxfix.push_back({&X.img, hx.begin()});
+            for (size_t hb = 0; hb < nh / 32; ++hb) {
+                for (int kc = 0; kc < 8; ++kc)
+                    hx.unit([&](int i, int hh, int e) { return w1v[(32 * hb + i) * cp + 16 * kc + 8 * hh + e] * s1; });
+                for (int cc = 0; cc < 2; ++cc)
+                    for (int ob = 0; ob < 4; ++ob)
+                        hx.unit([&](int j, int hh, int e) {
+                            return w2[(size_t)(32 * ob + j) * nh + 32 * hb + 16 * cc + (e & 3) + 8 * (e >> 2) + 4 * hh] * s2; });
+            }
+            std::vector<float> b1s(nh), b2s(cp);
+            for (size_t r = 0; r < nh; ++r) b1s[r] = b1v[r] * HX_SX * s1;
+            for (size_t r = 0; r < cp; ++r) b2s[r] = b2[r] * sh * s2;
+            slot(&X.b1s, img.raw(b1s.data(), nh)); slot(&X.b2s, img.raw(b2s.data(), cp));
         }
         slot(&L.pt_w2, img.pack(w2, (int)cp, (int)nh)); slot(&L.pt_b2, img.raw(b2, cp));
     }
@@ -307,6 +415,11 @@ int genie_load_weights(genie_handle_t h, const float* blob, size_t n_floats) {
     HIP_TRY(h, hipMemcpy(h->wdev, img.data.data(), img.data.size() * sizeof(float), hipMemcpyHostToDevice));
     h->wdev_floats = img.data.size();
     for (auto& f : fix) *f.first = h->wdev + f.second;
+    if (h->hxdev) { hipFree(h->hxdev); h->hxdev = nullptr; }
+    hx.begin();
+    HIP_TRY(h, hipMalloc((void**)&h->hxdev, hx.d.size() * 2 + 256));
+    HIP_TRY(h, hipMemcpy(h->hxdev, hx.d.data(), hx.d.size() * 2, hipMemcpyHostToDevice));
+    for (auto& f : hxfix) *f.first = h->hxdev + f.second;
     h->have_weights = true;
     return GENIE_OK;
 }

@@ -1,0 +1,661 @@
+// Pair-stack GEMM kernels in "hx" arithmetic (hx.h): the WL structure of pair_wl_kernels.hip
+// (a wave owns a 32-pair tile in fragment registers, weights arrive through LDS-DMA stages, the
+// work-groups are persistent) with every f32 GEMM carried by three f16 MFMAs on split operands.
+// 16x less matrix-pipe time per f32 FLOP than v_mfma_f32_32x32x2_f32 x 3 products = 5.3x, and the
+// VALU work (LayerNorm, splits, gates) now overlaps the MFMAs instead of competing for the FP32 lanes.
+#include <stdlib.h>
+#include "hx.h"
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t hx_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void hx_dma(rsrc_t r, unsigned char* lds_wave_base, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void hx_store(rsrc_t r, float v, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ void hx_store_u(rsrc_t r, unsigned v, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(v, r, voff, soff, 0);
+}
+__device__ __forceinline__ float hx_load(rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+#define UNI(x) __builtin_amdgcn_readfirstlane(x)
+#define PIPE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define HX_LDS_BYTES (2 * HX_STAGE_BYTES + 2048)
+
+__device__ __forceinline__ void hx_stage_landed() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void hx_stage_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Row tile -> normalised, scaled, split fragments.  Lane (p, h) owns channels 16kc + 8h .. +7 of
+// row p for kc = 0..7 (the B / A operand slots of k-chunk kc).  LayerNorm over the 128 channels =
+// this lane's 64 + its partner's (lane ^ 32); affine folded into the weights on the host.
+__device__ __forceinline__ void hx_load_rows(float4 (&raw)[16], const float* __restrict__ rowp, int h) {
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) {
+        raw[2 * kc] = *reinterpret_cast<const float4*>(rowp + 16 * kc + 8 * h);
+        raw[2 * kc + 1] = *reinterpret_cast<const float4*>(rowp + 16 * kc + 8 * h + 4);
+    }
+}
+__device__ __forceinline__ void hx_norm_split(h8 (&xh)[8], h8 (&xl)[8], float4 (&raw)[16], float sx) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += (raw[q].x + raw[q].y) + (raw[q].z + raw[q].w);
+    s += __shfl_xor(s, 32);
+    const float mean = s * (1.0f / 128.0f);
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        raw[q].x -= mean; raw[q].y -= mean; raw[q].z -= mean; raw[q].w -= mean;
+        ss += (raw[q].x * raw[q].x + raw[q].y * raw[q].y) + (raw[q].z * raw[q].z + raw[q].w * raw[q].w);
+    }
+    ss += __shfl_xor(ss, 32);
+    const float sc = sx / sqrtf(ss * (1.0f / 128.0f) + GENIE_LN_EPS);
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) {
+        const float x[8] = {raw[2 * kc].x * sc, raw[2 * kc].y * sc, raw[2 * kc].z * sc, raw[2 * kc].w * sc,
+                            raw[2 * kc + 1].x * sc, raw[2 * kc + 1].y * sc, raw[2 * kc + 1].z * sc, raw[2 * kc + 1].w * sc};
+        hx_split8(x, xh[kc], xl[kc]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pair transition + end-of-layer mask (modules/pair_transition.py:48-56, pair_transform_net.py:116-117):
+//   z = (z + W2 relu(W1 LN(z) + b1) + b2) * mask.
+// Stage = hidden block of 32: units 0..7 = W1 k-chunks (A operand: rows = hidden units),
+// units 8..15 = W2 (k-chunk c of the block, output block ob) at 8 + 4c + ob (B operand, chained-k
+// permutation).  D'[hidden][pair] = Sx S1 (W1 zn + b1) accumulates from the scaled bias; relu and
+// the rescale c1 = Sh / (Sx S1) give the second GEMM's A operand; out = acc * c2 (c2 = 1 / (Sh S2)).
+// ---------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_pair_transition_hx(
+    float* __restrict__ z, const float* __restrict__ rmask, const unsigned char* __restrict__ wimg,
+    const float* __restrict__ b1s, const float* __restrict__ b2s, int N, long long M, int n_hb, float sx, float c1, float c2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
+    float* sb1 = reinterpret_cast<float*>(smb + 2 * HX_STAGE_BYTES);
+    const int lane = threadIdx.x & 63, wave = UNI(threadIdx.x >> 6);
+    const int h = lane >> 5, pl = lane & 31;
+    const int n_wt = (int)((M + 31) / 32);
+    const int n_tiles = (n_wt + NW - 1) / NW;
+    const rsrc_t rw = hx_rsrc(wimg, (unsigned)(n_hb * HX_STAGE_BYTES));
+    const rsrc_t rz = hx_rsrc(z, (unsigned)(M * 512));               // rows >= M fall off the end: loads give 0, stores drop
+    const rsrc_t rnull = hx_rsrc(z, 0u);
+    const int lane16 = lane * 16;
+    constexpr int PW = 32 / NW;                   // 1-KiB pieces of a stage per wave
+    auto issue = [&](int hb, int buf) {
+#pragma unroll
+        for (int q = 0; q < PW; ++q) {
+            const int p = PW * wave + q;
+            hx_dma(rw, smb + buf * HX_STAGE_BYTES + p * 1024, lane16, hb * HX_STAGE_BYTES + p * 1024);
+        }
+    };
+    auto row_ptr = [&](int tile) {                // this lane's row of wave-tile NW tile + wave (clamped: always readable)
+        const long long r0 = (long long)min(tile * NW + wave, n_wt - 1) * 32;
+        return z + (r0 + min(pl, (int)min((long long)32, M - r0) - 1)) * 128;
+    };
+    int tile = blockIdx.x;
+    issue(0, 0);
+    for (int u = threadIdx.x; u < n_hb * 32; u += NW * 64) sb1[u] = b1s[u];
+    const float cb0 = b2s[pl], cb1 = b2s[32 + pl], cb2 = b2s[64 + pl], cb3 = b2s[96 + pl];
+    __syncthreads();
+#pragma unroll 1
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int wt_raw = tile * NW + wave;
+        const bool act = wt_raw < n_wt;
+        const long long row0 = (long long)(act ? wt_raw : n_wt - 1) * 32;
+        const int nrows = (int)min((long long)32, M - row0);
+        const bool more = tile + (int)gridDim.x < n_tiles;
+        float m_own = 0.f;
+        if (pl < nrows) {
+            const long long idx = row0 + pl;
+            const int bb = (int)(idx / ((long long)N * N));
+            const int rem = (int)(idx - (long long)bb * N * N);
+            m_own = rmask[bb * N + rem / N] * rmask[bb * N + rem % N];
+        }
+        h8 zh[8], zl[8];
+        {
+            float4 raw[16];
+            hx_load_rows(raw, row_ptr(tile), h);
+            hx_norm_split(zh, zl, raw, sx);
+        }
+        f32x16 o[4];
+        {
+            float e0 = cb0, e1 = cb1, e2 = cb2, e3 = cb3;
+            asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));   // keep hipcc from hoisting (and spilling) the splats
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[0][r] = e0; o[1][r] = e1; o[2][r] = e2; o[3][r] = e3; }
+        }
+#pragma unroll 1
+        for (int hb = 0; hb < n_hb; ++hb) {
+            if (hb + 1 < n_hb) issue(hb + 1, (hb + 1) & 1);
+            else if (more) issue(0, 0);
+            const unsigned char* stage = smb + (hb & 1) * HX_STAGE_BYTES;
+            f32x16 d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = sb1[hb * 32 + acc_row(r, lane)];
+            {
+                h8 wh = hx_frag(stage, 0, 0, lane), wl = hx_frag(stage, 0, 1, lane);
+#pragma unroll
+                for (int kc = 0; kc < 8; ++kc) {
+                    const h8 nh = hx_frag(stage, min(kc + 1, 7), 0, lane), nl = hx_frag(stage, min(kc + 1, 7), 1, lane);
+                    PIPE_FENCE();
+                    MFH3(wh, wl, zh[kc], zl[kc], d);
+                    PIPE_FENCE();
+                    wh = nh; wl = nl;
+                }
+            }
+            h8 ah[2], al[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = fmaxf(d[8 * c + e] * c1, 0.f);
+                hx_split8(x, ah[c], al[c]);
+            }
+            {
+                h8 bh = hx_frag(stage, 8, 0, lane), bl = hx_frag(stage, 8, 1, lane);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const h8 nh = hx_frag(stage, 8 + min(u + 1, 7), 0, lane), nl = hx_frag(stage, 8 + min(u + 1, 7), 1, lane);
+                    PIPE_FENCE();
+                    MFH3(ah[u >> 2], al[u >> 2], bh, bl, o[u & 3]);
+                    PIPE_FENCE();
+                    bh = nh; bl = nl;
+                }
+            }
+            __syncthreads();
+        }
+        // epilogue: row t = acc_row(r, lane) of the tile, channel 32 ob + pl
+        const rsrc_t rzz = act ? rz : rnull;
+        const int voff = (4 * h * 128 + pl) * 4;
+        const int srow0 = (int)(row0 * 512);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rc = (r & 3) + 8 * (r >> 2);
+            const float m = __shfl(m_own, rc + 4 * h);
+            const int so = srow0 + rc * 512;
+            const float z0 = hx_load(rzz, voff, so), z1 = hx_load(rzz, voff, so + 128), z2 = hx_load(rzz, voff, so + 256),
+                        z3 = hx_load(rzz, voff, so + 384);
+            const float v0 = o[0][r], v1 = o[1][r], v2 = o[2][r], v3 = o[3][r];
+            hx_store(rzz, fmaf(v0, c2, z0) * m, voff, so);
+            hx_store(rzz, fmaf(v1, c2, z1) * m, voff, so + 128);
+            hx_store(rzz, fmaf(v2, c2, z2) * m, voff, so + 256);
+            hx_store(rzz, fmaf(v3, c2, z3) * m, voff, so + 384);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Triangle multiplication, projections (modules/triangular_multiplicative_update.py:93-103):
+//   a = (W_ap zn + b) sigmoid(W_ag zn + b) mask,  b likewise;  zn = LN_in(z).
+// Stage = pass: units 2kc = the pass's 32 projection rows, 2kc + 1 = its 32 gate rows (pre-scaled by
+// -log2 e), k-chunk kc.  D rows = channels, D cols = pairs, so every store is a 128-B run of the
+// channel-major operand image the contraction reads; a and b are stored already SPLIT
+// (hi | lo << 16 of a S_a), 4 bytes per element as before.
+// ---------------------------------------------------------------------------------------------
+template <bool OUTGOING, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_proj_hx(
+    const float* __restrict__ z, const float* __restrict__ rmask, const unsigned char* __restrict__ wimg,
+    const float* __restrict__ bias, unsigned* __restrict__ acm, unsigned* __restrict__ bcm, int N, int NP, int n_wtiles,
+    unsigned cm_bytes, float sx, float cpa, float cpb, float cg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
+    float* sbias = reinterpret_cast<float*>(smb + 2 * HX_STAGE_BYTES);      // [512]
+    const int lane = threadIdx.x & 63, wave = UNI(threadIdx.x >> 6);
+    const int h = lane >> 5, pl = lane & 31;
+    const int ntile = (N + 31) >> 5;
+    const int n_tiles = (n_wtiles + NW - 1) / NW;
+    const rsrc_t rw = hx_rsrc(wimg, 8 * HX_STAGE_BYTES);
+    const rsrc_t ra = hx_rsrc(acm, cm_bytes), rb = hx_rsrc(bcm, cm_bytes);
+    const int lane16 = lane * 16;
+    const int sstride = NP * NP * 4;                      // bytes per channel
+    constexpr int PW = 32 / NW;
+    auto issue = [&](int pass, int buf) {
+#pragma unroll
+        for (int q = 0; q < PW; ++q) {
+            const int p = PW * wave + q;
+            hx_dma(rw, smb + buf * HX_STAGE_BYTES + p * 1024, lane16, pass * HX_STAGE_BYTES + p * 1024);
+        }
+    };
+    auto row_ptr = [&](int tile) {                        // this lane's row of wave-tile NW tile + wave (clamped: always readable)
+        const int wt = min(tile * NW + wave, n_wtiles - 1);
+        const int st = wt % ntile, line = (wt / ntile) % N, b = wt / (ntile * N);
+        const int pr = min(pl, min(32, N - st * 32) - 1);
+        return OUTGOING ? z + (((size_t)b * N + line) * N + st * 32 + pr) * 128
+                        : z + (((size_t)b * N + st * 32 + pr) * N + line) * 128;
+    };
+    int tile = blockIdx.x;
+    issue(0, 0);
+    for (int u = threadIdx.x; u < 512; u += NW * 64) sbias[u] = bias[u];
+    __syncthreads();
+#pragma unroll 1
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int wt_raw = tile * NW + wave;
+        const bool act = wt_raw < n_wtiles;
+        const int wt = act ? wt_raw : n_wtiles - 1;      // idle waves shadow the last tile (stores dropped)
+        const int st = wt % ntile, line = (wt / ntile) % N, b = wt / (ntile * N);
+        const int t0 = st * 32;
+        const int nvalid = act ? min(32, N - t0) : 0;
+        const float msk = (pl < nvalid) ? rmask[b * N + line] * rmask[b * N + t0 + pl] : 0.f;
+        const float ma = msk * cpa, mb = msk * cpb;
+        // channel-major store: element ((b*128 + ch)*NP + line)*NP + t0 + pl, ch = 32 (pass & 3) + row
+        const int voff = (pl < nvalid) ? (4 * h * NP * NP + pl) * 4 : 0x7FFFFFF0;   // out-of-range offset: store dropped
+        const int sbase = ((b * 128 * NP + line) * NP + t0) * 4;
+        const bool more = tile + (int)gridDim.x < n_tiles;
+        h8 zh[8], zl[8];
+        {
+            float4 raw[16];
+            hx_load_rows(raw, row_ptr(tile), h);
+            hx_norm_split(zh, zl, raw, sx);
+        }
+#pragma unroll 1
+        for (int pass = 0; pass < 8; ++pass) {
+            if (pass + 1 < 8) issue(pass + 1, (pass + 1) & 1);
+            else if (more) issue(0, 0);
+            const unsigned char* stage = smb + (pass & 1) * HX_STAGE_BYTES;
+            const float* sb = sbias + pass * 32;
+            f32x16 ap, ag;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ap[r] = sb[acc_row(r, lane)]; ag[r] = sb[256 + acc_row(r, lane)]; }
+            {
+                h8 ph = hx_frag(stage, 0, 0, lane), pq = hx_frag(stage, 0, 1, lane), gh = hx_frag(stage, 1, 0, lane),
+                   gq = hx_frag(stage, 1, 1, lane);
+#pragma unroll
+                for (int kc = 0; kc < 8; ++kc) {
+                    const int kn = min(kc + 1, 7);
+                    const h8 nph = hx_frag(stage, 2 * kn, 0, lane), npq = hx_frag(stage, 2 * kn, 1, lane),
+                             ngh = hx_frag(stage, 2 * kn + 1, 0, lane), ngq = hx_frag(stage, 2 * kn + 1, 1, lane);
+                    PIPE_FENCE();
+                    MFH3(ph, pq, zh[kc], zl[kc], ap);
+                    MFH3(gh, gq, zh[kc], zl[kc], ag);
+                    PIPE_FENCE();
+                    ph = nph; pq = npq; gh = ngh; gq = ngq;
+                }
+            }
+            hx_stage_landed();
+            const rsrc_t rd = pass < 4 ? ra : rb;
+            const float pm = pass < 4 ? ma : mb;
+            const int so = sbase + (pass & 3) * 32 * sstride;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {   // register r holds channel rows (r&3) + 8(r>>2) [+4 for the upper half-wave: in voff]
+                const float pv = ap[r], gv = ag[r];
+                const float v = pv * pm * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gv * cg));
+                hx_store_u(rd, hx_pack1(v), voff, so + ((r & 3) + 8 * (r >> 2)) * sstride);
+            }
+            hx_stage_barrier();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Triangle multiplication, contraction (triangular_multiplicative_update.py:57-82):
+//   x_cm[bc][i][j] = sum_k a_cm[bc][i][k] b_cm[bc][j][k] / (S_a S_b),  operands stored split.
+// WG tile (64 WT)^2, 4 waves of (32 WT)^2, K streamed 16 at a time: each thread loads 16 B (4 split
+// values) per 64 rows, de-interleaves them with two v_perm (hi halves / lo halves) and writes the
+// two 8-B pieces into the hi / lo planes of the double-buffered LDS stage (row stride 48 B: the
+// ds_read_b128 fragment reads are conflict free).  HBM-bound in this arithmetic (36 FLOP/B).
+// Persistent + XCD-aware tile order as in pair_kernels.hip.
+// ---------------------------------------------------------------------------------------------
+#define CX_ROWB 48
+template <int WT>
+__global__ __launch_bounds__(256, 2) void k_trimul_contract_hx(const unsigned* __restrict__ acm, const unsigned* __restrict__ bcm,
+                                                               float* __restrict__ xcm, int NP, int n_mat, unsigned cm_bytes, float cx) {
+    constexpr int TM = 64 * WT;
+    constexpr int PLANE = TM * CX_ROWB;                 // bytes of one (operand, half) plane
+    extern __shared__ __attribute__((aligned(16))) unsigned char smb[];   // [2 buf][A hi | A lo | B hi | B lo]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = UNI(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles = (NP + TM - 1) / TM;
+    const int T = tiles * tiles;
+    const int n_tiles = T * ((n_mat + 7) / 8) * 8;
+    const int nk = NP / 16;
+    const rsrc_t ra = hx_rsrc(acm, cm_bytes), rb = hx_rsrc(bcm, cm_bytes), rx = hx_rsrc(xcm, cm_bytes);
+    const int lr = tid >> 2, c4 = tid & 3;
+    const int vload = (lr * NP + c4 * 4) * 4;           // per-lane byte offset inside a 64-row block of a panel
+    const int slds = lr * CX_ROWB + c4 * 8;
+    u32x4 rA[WT], rB[WT];
+
+    auto decode = [&](int w, int& mi, int& i0, int& j0) {       // tile id -> (matrix, tile origin)
+        const int grp = w / (8 * T), rem = w % (8 * T);
+        const int tile = rem >> 3;
+        mi = grp * 8 + (rem & 7);
+        i0 = (tile / tiles) * TM;
+        j0 = (tile % tiles) * TM;
+    };
+    auto gload = [&](int w, int kc) {
+        int mi, i0, j0;
+        decode(w, mi, i0, j0);
+        const int mclamp = min(mi, n_mat - 1);
+        const int mbase = mclamp * NP * NP * 4 + kc * 64;
+#pragma unroll
+        for (int u = 0; u < WT; ++u) {     // rows past NP: voffset pushed out of the buffer -> the load returns 0
+            const int va = (i0 + 64 * u + lr < NP) ? vload : 0x7FFFFFF0, vb = (j0 + 64 * u + lr < NP) ? vload : 0x7FFFFFF0;
+            rA[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, va, mbase + (i0 + 64 * u) * NP * 4, 0));
+            rB[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, vb, mbase + (j0 + 64 * u) * NP * 4, 0));
+        }
+    };
+    auto swrite = [&](int buf) {
+        unsigned char* sa = smb + buf * 4 * PLANE + slds;
+#pragma unroll
+        for (int u = 0; u < WT; ++u) {
+            uint2 ahi, alo, bhi, blo;
+            ahi.x = __builtin_amdgcn_perm(rA[u].y, rA[u].x, 0x05040100u); ahi.y = __builtin_amdgcn_perm(rA[u].w, rA[u].z, 0x05040100u);
+            alo.x = __builtin_amdgcn_perm(rA[u].y, rA[u].x, 0x07060302u); alo.y = __builtin_amdgcn_perm(rA[u].w, rA[u].z, 0x07060302u);
+            bhi.x = __builtin_amdgcn_perm(rB[u].y, rB[u].x, 0x05040100u); bhi.y = __builtin_amdgcn_perm(rB[u].w, rB[u].z, 0x05040100u);
+            blo.x = __builtin_amdgcn_perm(rB[u].y, rB[u].x, 0x07060302u); blo.y = __builtin_amdgcn_perm(rB[u].w, rB[u].z, 0x07060302u);
+            *reinterpret_cast<uint2*>(sa + 64 * u * CX_ROWB) = ahi;
+            *reinterpret_cast<uint2*>(sa + PLANE + 64 * u * CX_ROWB) = alo;
+            *reinterpret_cast<uint2*>(sa + 2 * PLANE + 64 * u * CX_ROWB) = bhi;
+            *reinterpret_cast<uint2*>(sa + 3 * PLANE + 64 * u * CX_ROWB) = blo;
+        }
+    };
+
+    f32x16 acc[WT][WT];
+#pragma unroll
+    for (int m = 0; m < WT; ++m)
+#pragma unroll
+        for (int n = 0; n < WT; ++n) acc[m][n] = zero16();
+
+    int w = blockIdx.x;
+    if (w >= n_tiles) return;
+    const int my_tiles = (n_tiles - 1 - w) / gridDim.x + 1;
+    const int total = my_tiles * nk;
+    gload(w, 0);
+    swrite(0);
+    __syncthreads();
+    int kc = 0;
+    const int foff = (lane & 31) * CX_ROWB + (lane >> 5) * 16;
+    for (int it = 0; it < total; ++it) {
+        const bool last_chunk = kc == nk - 1;
+        const int wn_next = last_chunk ? w + gridDim.x : w;
+        const int kc_next = last_chunk ? 0 : kc + 1;
+        if (it + 1 < total) gload(wn_next, kc_next);
+        const unsigned char* sa = smb + (it & 1) * 4 * PLANE + foff;
+        h8 ah[WT], al[WT], bh[WT], bl[WT];
+#pragma unroll
+        for (int m = 0; m < WT; ++m) {
+            ah[m] = *reinterpret_cast<const h8*>(sa + (wm * WT + m) * 32 * CX_ROWB);
+            al[m] = *reinterpret_cast<const h8*>(sa + PLANE + (wm * WT + m) * 32 * CX_ROWB);
+        }
+#pragma unroll
+        for (int n = 0; n < WT; ++n) {
+            bh[n] = *reinterpret_cast<const h8*>(sa + 2 * PLANE + (wn * WT + n) * 32 * CX_ROWB);
+            bl[n] = *reinterpret_cast<const h8*>(sa + 3 * PLANE + (wn * WT + n) * 32 * CX_ROWB);
+        }
+#pragma unroll
+        for (int m = 0; m < WT; ++m)
+#pragma unroll
+            for (int n = 0; n < WT; ++n) MFH3(ah[m], al[m], bh[n], bl[n], acc[m][n]);
+        if (last_chunk) {       // store the finished tile (row = acc_row(r): 4 (lane>>5) in voffset, the rest scalar)
+            int mi, i0, j0;
+            decode(w, mi, i0, j0);
+            if (mi < n_mat) {
+                const int vst = ((4 * (lane >> 5)) * NP + (lane & 31)) * 4;
+#pragma unroll
+                for (int m = 0; m < WT; ++m)
+#pragma unroll
+                    for (int n = 0; n < WT; ++n) {
+                        const int ib = i0 + (wm * WT + m) * 32, jb = j0 + (wn * WT + n) * 32;
+                        if (ib < NP && jb < NP) {
+                            const int sbase = ((mi * NP + ib) * NP + jb) * 4;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float v = acc[m][n][r] * cx;     // (bit_cast straight from a vector element picks element 0)
+                                hx_store(rx, v, vst, sbase + ((r & 3) + 8 * (r >> 2)) * NP * 4);
+                            }
+                        }
+                        acc[m][n] = zero16();
+                    }
+            }
+        }
+        if (it + 1 < total) swrite((it + 1) & 1);
+        __syncthreads();
+        w = wn_next;
+        kc = kc_next;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Triangle multiplication, output (modules/triangular_multiplicative_update.py:105-108 + residual):
+//   z += (W_z LN_out(x) + b_z) * sigmoid(W_g LN_in(z) + b_g).
+// A operand = the pair tile (zn, then xn), B = weights; stages W_g{0,1}, W_z{0,1}, W_g{2,3}, W_z{2,3},
+// unit = 8 (output block within the stage) + k-chunk.  x arrives channel-major: lane (p, h) reads
+// x[c][p] for its 64 channels c = 16kc + 8h + e (each load = two 128-B runs).
+// ---------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_out_hx(
+    float* __restrict__ z, const float* __restrict__ xcm, const unsigned char* __restrict__ wimg,
+    const float* __restrict__ bgs, const float* __restrict__ bzs, int N, int NP, int n_wtiles, unsigned cm_bytes,
+    unsigned z_bytes, float sx, float cg, float cz) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
+    const int lane = threadIdx.x & 63, wave = UNI(threadIdx.x >> 6);
+    const int h = lane >> 5, pl = lane & 31;
+    const int ntile = (N + 31) >> 5;
+    const int n_tiles = (n_wtiles + NW - 1) / NW;
+    const rsrc_t rw = hx_rsrc(wimg, 4 * HX_STAGE_BYTES);
+    const rsrc_t rx = hx_rsrc(xcm, cm_bytes), rz = hx_rsrc(z, z_bytes);
+    const int lane16 = lane * 16;
+    constexpr int PW = 32 / NW;
+    auto issue = [&](int s, int buf) {
+#pragma unroll
+        for (int q = 0; q < PW; ++q) {
+            const int p = PW * wave + q;
+            hx_dma(rw, smb + buf * HX_STAGE_BYTES + p * 1024, lane16, s * HX_STAGE_BYTES + p * 1024);
+        }
+    };
+    auto row_ptr = [&](int tile) {              // this lane's z row of wave-tile NW tile + wave (clamped: always readable)
+        const int wt = min(tile * NW + wave, n_wtiles - 1);
+        const int st = wt % ntile, i = (wt / ntile) % N, b = wt / (ntile * N);
+        const int pr = min(pl, min(32, N - st * 32) - 1);
+        return z + (((size_t)b * N + i) * N + st * 32 + pr) * 128;
+    };
+    int tile = blockIdx.x;
+    issue(0, 0);
+    __syncthreads();
+#pragma unroll 1
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int wt_raw = tile * NW + wave;
+        const bool act = wt_raw < n_wtiles;
+        const int wt = act ? wt_raw : n_wtiles - 1;
+        const int st = wt % ntile, i = (wt / ntile) % N, b = wt / (ntile * N);
+        const int t0 = st * 32;
+        const int nvalid = act ? min(32, N - t0) : 0;
+        const int prow0 = (b * N + i) * N + t0;                  // first pair row of the tile
+        const bool more = tile + (int)gridDim.x < n_tiles;
+        h8 zh[8], zl[8], xh[8], xl[8];
+        {
+            float4 raw[16];
+            hx_load_rows(raw, row_ptr(tile), h);
+            hx_norm_split(zh, zl, raw, sx);
+        }
+        {   // x_cm[((b*128 + c)*NP + i)*NP + t0 + pl], c = 16kc + 8h + e   (t0 + pl < NP always)
+            float4 raw[16];
+            const int cs = NP * NP * 4;
+            const int vx = (8 * h * NP * NP + pl) * 4;
+            const int sxo = ((b * 128 * NP + i) * NP + t0) * 4;
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                raw[2 * kc].x = hx_load(rx, vx, sxo + (16 * kc + 0) * cs); raw[2 * kc].y = hx_load(rx, vx, sxo + (16 * kc + 1) * cs);
+                raw[2 * kc].z = hx_load(rx, vx, sxo + (16 * kc + 2) * cs); raw[2 * kc].w = hx_load(rx, vx, sxo + (16 * kc + 3) * cs);
+                raw[2 * kc + 1].x = hx_load(rx, vx, sxo + (16 * kc + 4) * cs); raw[2 * kc + 1].y = hx_load(rx, vx, sxo + (16 * kc + 5) * cs);
+                raw[2 * kc + 1].z = hx_load(rx, vx, sxo + (16 * kc + 6) * cs); raw[2 * kc + 1].w = hx_load(rx, vx, sxo + (16 * kc + 7) * cs);
+            }
+            hx_norm_split(xh, xl, raw, sx);
+        }
+        const int voff = (4 * h * 128 + pl) * 4;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x16 ga, gb;
+            {   // gate: A = zn fragments (i = pair), B = W_g (j = channel)
+                issue(2 * half + 1, 1);
+                const unsigned char* stage = smb;
+                float c0 = bgs[(2 * half) * 32 + pl], c1 = bgs[(2 * half + 1) * 32 + pl];
+                asm volatile("" : "+v"(c0), "+v"(c1));      // keep hipcc from hoisting (and spilling) the 16-register splats
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { ga[r] = c0; gb[r] = c1; }
+                h8 f0 = hx_frag(stage, 0, 0, lane), f0l = hx_frag(stage, 0, 1, lane), f1 = hx_frag(stage, 8, 0, lane),
+                   f1l = hx_frag(stage, 8, 1, lane);
+#pragma unroll
+                for (int kc = 0; kc < 8; ++kc) {
+                    const int kn = min(kc + 1, 7);
+                    const h8 n0 = hx_frag(stage, kn, 0, lane), n0l = hx_frag(stage, kn, 1, lane), n1 = hx_frag(stage, 8 + kn, 0, lane),
+                             n1l = hx_frag(stage, 8 + kn, 1, lane);
+                    PIPE_FENCE();
+                    MFH3(zh[kc], zl[kc], f0, f0l, ga);
+                    MFH3(zh[kc], zl[kc], f1, f1l, gb);
+                    PIPE_FENCE();
+                    f0 = n0; f0l = n0l; f1 = n1; f1l = n1l;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    ga[r] = cz * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ga[r] * cg));
+                    gb[r] = cz * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gb[r] * cg));
+                }
+                __syncthreads();
+            }
+            {   // update of channel blocks 2 half, 2 half + 1
+                if (half == 0) issue(2, 0);
+                else if (more) issue(0, 0);
+                const unsigned char* stage = smb + HX_STAGE_BYTES;
+                const int ob = 2 * half;
+                f32x16 a0, a1;
+                float c0 = bzs[ob * 32 + pl], c1 = bzs[(ob + 1) * 32 + pl];
+                asm volatile("" : "+v"(c0), "+v"(c1));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { a0[r] = c0; a1[r] = c1; }
+                h8 f0 = hx_frag(stage, 0, 0, lane), f0l = hx_frag(stage, 0, 1, lane), f1 = hx_frag(stage, 8, 0, lane),
+                   f1l = hx_frag(stage, 8, 1, lane);
+#pragma unroll
+                for (int kc = 0; kc < 8; ++kc) {
+                    const int kn = min(kc + 1, 7);
+                    const h8 n0 = hx_frag(stage, kn, 0, lane), n0l = hx_frag(stage, kn, 1, lane), n1 = hx_frag(stage, 8 + kn, 0, lane),
+                             n1l = hx_frag(stage, 8 + kn, 1, lane);
+                    PIPE_FENCE();
+                    MFH3(xh[kc], xl[kc], f0, f0l, a0);
+                    MFH3(xh[kc], xl[kc], f1, f1l, a1);
+                    PIPE_FENCE();
+                    f0 = n0; f0l = n0l; f1 = n1; f1l = n1l;
+                }
+                hx_stage_landed();
+                // residual + store, 8 rows (16 loads) in flight at a time; rows past the tile's valid pairs belong to
+                // the next line: their offset is pushed out of the buffer (load gives 0, store is dropped)
+                const int h4 = 4 * h;
+#pragma unroll
+                for (int r0 = 0; r0 < 16; r0 += 8) {
+                    float zr0[8], zr1[8];
+                    int vo[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int rc = ((r0 + q) & 3) + 8 * ((r0 + q) >> 2);
+                        const int so = (prow0 + rc) * 512 + ob * 128;
+                        vo[q] = (h4 < nvalid - rc) ? voff : 0x7FFFFFF0;
+                        zr0[q] = hx_load(rz, vo[q], so);
+                        zr1[q] = hx_load(rz, vo[q], so + 128);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int rc = ((r0 + q) & 3) + 8 * ((r0 + q) >> 2);
+                        const int so = (prow0 + rc) * 512 + ob * 128;
+                        const float u0 = a0[r0 + q], u1 = a1[r0 + q], g0 = ga[r0 + q], g1 = gb[r0 + q];
+                        hx_store(rz, fmaf(u0, g0, zr0[q]), vo[q], so);
+                        hx_store(rz, fmaf(u1, g1, zr1[q]), vo[q], so + 128);
+                    }
+                    PIPE_FENCE();
+                }
+                hx_stage_barrier();
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+static int g_hx_cu = 0;
+static int hx_num_cu() {
+    if (!g_hx_cu) { int dev = 0; hipDeviceProp_t pr; (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&pr, dev); g_hx_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+    return g_hx_cu;
+}
+static int g_hx_nw = 0;      // waves per work-group: 8 (one WG per CU) or 4 (two)
+static int hx_nw() {
+    if (!g_hx_nw) { const char* e = getenv("GENIE_HX_WAVES"); g_hx_nw = (e && atoi(e) == 4) ? 4 : 8; }
+    return g_hx_nw;
+}
+static unsigned hx_grid(long long n_tiles, int nw) {
+    const long long cap = (nw == 8 ? 1LL : 2LL) * hx_num_cu();
+    return (unsigned)(n_tiles < cap ? n_tiles : cap);
+}
+
+void launch_pair_transition_hx(genie_ctx* h, hipStream_t st, const PairLayerW& w) {
+    const long long M = (long long)h->B * h->N * h->N;
+    const long long n_wt = (M + 31) / 32;
+    const int n_hb = h->d.pair_transition_n * 4;
+    const HxTransW& x = w.hx_pt;
+    if (hx_nw() == 8)
+        hipLaunchKernelGGL(k_pair_transition_hx<8>, dim3(hx_grid((n_wt + 7) / 8, 8)), dim3(512), HX_LDS_BYTES, st, h->p, h->rmaskf,
+                           x.img, x.b1s, x.b2s, h->N, M, n_hb, x.sx, x.c1, x.c2);
+    else
+        hipLaunchKernelGGL(k_pair_transition_hx<4>, dim3(hx_grid((n_wt + 3) / 4, 4)), dim3(256), HX_LDS_BYTES, st, h->p, h->rmaskf,
+                           x.img, x.b1s, x.b2s, h->N, M, n_hb, x.sx, x.c1, x.c2);
+}
+
+void launch_trimul_hx(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgoing) {
+    const int N = h->N, NP = h->NP, ntile = (N + 31) / 32;
+    const int n_wt = h->B * N * ntile;
+    const int nw = hx_nw();
+    const HxTriW& x = w.hx;
+    const unsigned cm_bytes = (unsigned)((size_t)h->B * 128 * NP * NP * 4);
+    unsigned* acm = reinterpret_cast<unsigned*>(h->acm);
+    unsigned* bcm = reinterpret_cast<unsigned*>(h->bcm);
+    {
+        ProfScope ps(h, st, KC_TRIMUL_PROJ);
+        const dim3 grid(hx_grid((n_wt + nw - 1) / nw, nw)), block(nw * 64);
+#define HX_PROJ(OUT, NWV) hipLaunchKernelGGL((k_trimul_proj_hx<OUT, NWV>), grid, block, HX_LDS_BYTES, st, h->p, h->rmaskf, x.img_proj, \
+                                             x.bias_proj, acm, bcm, N, NP, n_wt, cm_bytes, x.sx, x.cpa, x.cpb, x.cg)
+        if (outgoing) { if (nw == 8) HX_PROJ(true, 8); else HX_PROJ(true, 4); }
+        else          { if (nw == 8) HX_PROJ(false, 8); else HX_PROJ(false, 4); }
+#undef HX_PROJ
+    }
+    {
+        ProfScope ps(h, st, KC_TRIMUL_CONTRACT);
+        const int BC = h->B * h->d.c_hidden_mul;
+        const int ncu = hx_num_cu();
+        if (NP >= 128) {
+            const int tiles = (NP + 127) / 128;
+            const int n_tiles = tiles * tiles * ((BC + 7) / 8) * 8;
+            hipLaunchKernelGGL(k_trimul_contract_hx<2>, dim3(n_tiles < 3 * ncu ? n_tiles : 3 * ncu), dim3(256), 2 * 4 * 128 * CX_ROWB, st,
+                               acm, bcm, h->xcm, NP, BC, cm_bytes, x.cx);
+        } else {
+            const int tiles = (NP + 63) / 64;
+            const int n_tiles = tiles * tiles * ((BC + 7) / 8) * 8;
+            hipLaunchKernelGGL(k_trimul_contract_hx<1>, dim3(n_tiles < 4 * ncu ? n_tiles : 4 * ncu), dim3(256), 2 * 4 * 64 * CX_ROWB, st,
+                               acm, bcm, h->xcm, NP, BC, cm_bytes, x.cx);
+        }
+    }
+    {
+        ProfScope ps(h, st, KC_TRIMUL_OUT);
+        const unsigned z_bytes = (unsigned)((size_t)h->B * N * N * 512);
+        if (nw == 8)
+            hipLaunchKernelGGL(k_trimul_out_hx<8>, dim3(hx_grid((n_wt + 7) / 8, 8)), dim3(512), HX_LDS_BYTES, st, h->p, h->xcm, x.img_out,
+                               x.bgs, x.bzs, N, NP, n_wt, cm_bytes, z_bytes, x.sx, x.cgo, x.cz);
+        else
+            hipLaunchKernelGGL(k_trimul_out_hx<4>, dim3(hx_grid((n_wt + 3) / 4, 4)), dim3(256), HX_LDS_BYTES, st, h->p, h->xcm, x.img_out,
+                               x.bgs, x.bzs, N, NP, n_wt, cm_bytes, z_bytes, x.sx, x.cgo, x.cz);
+    }
+}
+
+void pair_hx_kernels_init() {
+#define HX_ATTR(k) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, HX_LDS_BYTES)
+    HX_ATTR((k_trimul_proj_hx<true, 8>)); HX_ATTR((k_trimul_proj_hx<true, 4>)); HX_ATTR((k_trimul_proj_hx<false, 8>)); HX_ATTR((k_trimul_proj_hx<false, 4>));
+    HX_ATTR(k_trimul_out_hx<8>); HX_ATTR(k_trimul_out_hx<4>);
+#undef HX_ATTR
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_transition_hx<8>), hipFuncAttributeMaxDynamicSharedMemorySize, HX_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_transition_hx<4>), hipFuncAttributeMaxDynamicSharedMemorySize, HX_LDS_BYTES);
+}

@@ -442,7 +442,9 @@ void launch_trimul_proj_wl(genie_ctx* h, hipStream_t st, const TriMulW& w, bool 
 void launch_trimul_out_wl(genie_ctx* h, hipStream_t st, const TriMulW& w);
 void launch_pair_transition_wl(genie_ctx* h, hipStream_t st, const PairLayerW& w);
 
+void launch_trimul_hx(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgoing);
 void launch_trimul(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgoing) {
+    if (h->hx) { launch_trimul_hx(h, st, w, outgoing); return; }
     const int N = h->N, NP = h->NP, ntile = (N + 63) / 64;
     {
         ProfScope ps(h, st, KC_TRIMUL_PROJ);
@@ -474,9 +476,11 @@ void launch_trimul(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgoing
     }
 }
 
+void launch_pair_transition_hx(genie_ctx* h, hipStream_t st, const PairLayerW& w);
 void launch_pair_transition(genie_ctx* h, hipStream_t st, const PairLayerW& w) {
     ProfScope ps(h, st, KC_PAIR_TRANSITION);
-    launch_pair_transition_wl(h, st, w);
+    if (h->hx) launch_pair_transition_hx(h, st, w);
+    else launch_pair_transition_wl(h, st, w);
 }
 
 void launch_ipa_bias(genie_ctx* h, hipStream_t st) {
@@ -489,9 +493,11 @@ void launch_ipa_bias(genie_ctx* h, hipStream_t st) {
 }
 
 void pair_wl_kernels_init();
+void pair_hx_kernels_init();
 // One-time opt-in to > 64 KiB dynamic LDS.
 void pair_kernels_init() {
     pair_wl_kernels_init();
+    pair_hx_kernels_init();
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_trimul_contract<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         2 * 2 * 128 * LDK * sizeof(float));
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_bias), hipFuncAttributeMaxDynamicSharedMemorySize,

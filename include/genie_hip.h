@@ -56,7 +56,7 @@ typedef struct {
 } genie_dims_t;
 
 /* The tensors of the reference's 12-key feature dict the denoiser reads
- * (genie/utils/feat_utils.py:304-321; model/*.py).  bool tensors are passed
+ * (genie/utils/feat_utils.py:304-321; model/ *.py).  bool tensors are passed
  * as their 1-byte storage. */
 typedef struct {
     const int32_t* aatype;               /* [B,N,20] */
