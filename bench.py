@@ -12,8 +12,14 @@ barrier / max and a trivial all_gather of the final C-alpha coordinates.
 
 Rank 0 prints ONE JSON line.  `value` = batch-steps/s summed over all ranks
 (x8 = structure-steps/s, also reported).  `roofline` prices the dominant kernel
-class against the fp32 MFMA peak; `cpu_baseline` times the oracle (the CPU
-restatement of the reference) on this host for one step of the same workload.
+class (largest time per step, HIP events on the launch stream) against the roof
+that bounds it: its algorithmic HBM bytes at 8 TB/s or its matrix FLOPs at the
+MFMA peak of the arithmetic in use, whichever takes longer (--math hx: three f16
+MFMAs per f32 product at 2.5 PFLOP/s; --math f32: v_mfma_f32 at 157.3 TFLOP/s).
+`traffic` = HBM bytes per launch from the committed rocprofv3 FETCH_SIZE /
+WRITE_SIZE passes (profiles/), null if that kernel was not profiled.
+`cpu_baseline` times the oracle (the CPU restatement of the reference) on this
+host for one step of the same workload.
 """
 import argparse
 import json
@@ -31,7 +37,28 @@ from genie2_amd.engine import GenieEngine  # noqa: E402
 from genie2_amd import features as F  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_F16_MFMA_TFLOPS = 2500.0     # same table, "Peak BF16/FP16 MFMA", dense
 PEAK_HBM_GBS = 8000.0
+PMC_TRAFFIC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
+KERNEL_OF_CLASS = {'trimul_proj': 'k_trimul_proj', 'trimul_contract': 'k_trimul_contract', 'trimul_out': 'k_trimul_out',
+                   'pair_transition': 'k_pair_transition'}
+
+
+def algorithmic_bytes(dims, B, N):
+    """HBM bytes per launch each pair-stack kernel class cannot avoid: every
+    [B,N,N,128] f32 tensor it consumes or produces once (split f16 pairs are 4 bytes too)."""
+    t = 4.0 * B * N * N * dims['c_p']
+    return {'trimul_proj': 3 * t, 'trimul_contract': 3 * t, 'trimul_out': 3 * t, 'pair_transition': 2 * t}
+
+
+def measured_traffic(cls, math):
+    """HBM bytes per launch from the committed PMC passes (None when this kernel was not profiled)."""
+    try:
+        d = json.load(open(PMC_TRAFFIC))[math]
+    except (OSError, KeyError, ValueError):
+        return None
+    v = [k for name, k in d.items() if name.startswith(KERNEL_OF_CLASS[cls])]
+    return sum(x['hbm_read_bytes'] + x['hbm_write_bytes'] for x in v) / len(v) if v else None
 
 
 def algorithmic_flops(dims, B, N):
@@ -111,6 +138,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-steps', type=int, default=3)
+    ap.add_argument('--math', choices=['hx', 'f32'], default=None, help='pair-stack arithmetic (default: library default, hx)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -127,7 +155,8 @@ def main():
     B, N, T = args.batch, args.length, dims['n_timestep']
     K, W = args.steps, args.warmup
     assert K + W <= T, 'steps + warmup must fit in T'
-    eng = GenieEngine(dims, pack.random_state_dict(dims, seed=0), dev)
+    eng = GenieEngine(dims, pack.random_state_dict(dims, seed=0), dev, math=args.math)
+    math = eng.math
     feats = F.convert_np_features_to_tensor(
         F.batchify_np_features([F.create_empty_np_features([N]) for _ in range(B)]), dev)
     eng.bind_features(feats)
@@ -176,20 +205,32 @@ def main():
         kern = {k: {'ms_per_launch': ms / max(cnt, 1), 'launches_per_step': cnt / P, 'ms_per_step': ms / P}
                 for k, (ms, cnt) in prof.items() if cnt}
         dom = max((k for k in kern if k in flops), key=lambda k: kern[k]['ms_per_step'])
-        ach = flops[dom] / (kern[dom]['ms_per_launch'] * 1e-3) / 1e12
-        roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
-                'avg_launch_ms': kern[dom]['ms_per_launch'], 'flop_per_launch': flops[dom]}
+        launch_s = kern[dom]['ms_per_launch'] * 1e-3
+        nbytes = algorithmic_bytes(dims, B, N)[dom]
+        mfma_flop = flops[dom] * (3.0 if math == 'hx' else 1.0)           # matrix-pipe FLOP per launch
+        mfma_peak = PEAK_F16_MFMA_TFLOPS if math == 'hx' else PEAK_FP32_MFMA_TFLOPS
+        t_mfma, t_hbm = mfma_flop / (mfma_peak * 1e12), nbytes / (PEAK_HBM_GBS * 1e9)
+        if t_hbm >= t_mfma:
+            ach = nbytes / launch_s / 1e9
+            roof = {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS}
+        else:
+            ach = mfma_flop / launch_s / 1e12
+            roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': mfma_peak, 'unit': 'TFLOP/s', 'frac': ach / mfma_peak}
+        roof.update({'traffic': measured_traffic(dom, math), 'avg_launch_ms': kern[dom]['ms_per_launch'],
+                     'algorithmic_bytes_per_launch': nbytes, 'algorithmic_flop_per_launch': flops[dom],
+                     'matrix_flop_per_launch': mfma_flop, 'floor_ms': {'hbm': t_hbm * 1e3, 'mfma': t_mfma * 1e3}})
         whole = step_flops(dims, B, N) * (K / dt) / 1e12
         out = {
             'metric': 'denoise-steps/sec (N=256, T=1000, batch=8)', 'value': value, 'unit': 'batch-steps/s',
             'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': dt / K * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if math == 'f32' else 'f32 (pair-stack products as 3 f16 MFMAs on 2xf16-split operands, f32 accumulate)',
+            'data': 'synthetic', 'math': math,
             'config': {'workload': f'unconditional N={N}, T={T}, batch={B} per GPU, random-init base Denoiser '
                                    f'(15.7M params), scale=0.6, reverse-loop steps {T - W}..{T - W - K + 1}',
                        'parallelism': f'replica per GPU x{world}, no data-path collective'},
             'structure_steps_per_s': value * B,
-            'whole_step_tflops': whole, 'whole_step_frac_of_fp32_mfma_peak': whole / PEAK_FP32_MFMA_TFLOPS,
+            'whole_step_tflops': whole,
             'finite': finite, 'roofline': roof,
             'kernels': {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in kern.items()},
         }

@@ -58,6 +58,8 @@ SYMBOLS = {
                                  C.c_void_p]),
     'genie_sample_loop': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    'genie_set_math': (C.c_int, [C.c_void_p, C.c_int]),
+    'genie_get_math': (C.c_int, [C.c_void_p]),
     'genie_profile_enable': (C.c_int, [C.c_void_p, C.c_int]),
     'genie_profile_read': (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                                      C.POINTER(C.c_int64), C.c_int]),

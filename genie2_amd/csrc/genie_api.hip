@@ -101,7 +101,7 @@ int genie_create(const genie_dims_t* dims, int device, genie_handle_t* out) {
     pair_kernels_init();
     {   // GENIE_MATH=f32: exact-f32 MFMA kernels; default: split-f16 ("hx", same accuracy class, see hx.h)
         const char* m = getenv("GENIE_MATH");
-        h->hx = m && !strcmp(m, "hx");
+        h->hx = !(m && !strcmp(m, "f32"));
     }
     *out = h;
     return GENIE_OK;
@@ -638,6 +638,14 @@ int genie_sample_loop(genie_handle_t h, genie_stream_t stream, float scale, cons
     HIP_TRY(h, hipGetLastError());
     return GENIE_OK;
 }
+
+// ------------------------------------------------------------------ arithmetic
+int genie_set_math(genie_handle_t h, int mode) {
+    if (!h || (mode != GENIE_MATH_F32 && mode != GENIE_MATH_HX)) return GENIE_E_ARG;
+    h->hx = mode == GENIE_MATH_HX;
+    return GENIE_OK;
+}
+int genie_get_math(genie_handle_t h) { return h && h->hx ? GENIE_MATH_HX : GENIE_MATH_F32; }
 
 // ------------------------------------------------------------------ measurement
 int genie_profile_enable(genie_handle_t h, int enable) {

@@ -36,33 +36,35 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // (a_hi + a_lo)(b_hi + b_lo) without the lo*lo term, small terms first
 #define MFH3(ah, al, bh, bl, c) do { MFH(al, bh, c); MFH(ah, bl, c); MFH(ah, bh, c); } while (0)
 
-// hi / lo halves of two f32 values (already scaled), packed: RTN both times
-__device__ __forceinline__ void hx_split2(float a, float b, unsigned& hi, unsigned& lo) {
-    h2 h;
-    h.x = (_Float16)a; h.y = (_Float16)b;
-    const float ra = a - (float)h.x, rb = b - (float)h.y;
-    h2 l;
-    l.x = (_Float16)ra; l.y = (_Float16)rb;
-    hi = __builtin_bit_cast(unsigned, h);
-    lo = __builtin_bit_cast(unsigned, l);
+// The splits are written with v_fma_mix* directly: hi = f16(x s) and lo = f16(x s - hi) are both taken
+// from the EXACT product x s (one rounding each), and -- the reason for the asm -- from the SAME hi.
+// Left to hipcc, `(_Float16)(x*s)` is sometimes contracted into v_fma_mixlo (exact product) for one
+// use and v_cvt_pk_f16_f32 of the rounded f32 product for another; when the two disagree (double
+// rounding) the pair is off by a whole f16 ulp of hi, i.e. 2^-11 instead of 2^-22.
+// (hi, lo) of a*s and b*s, packed with a in the low half
+__device__ __forceinline__ void hx_split2(float a, float b, float s, unsigned& hi, unsigned& lo) {
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(a), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(b), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(a), "v"(s), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(b), "v"(s), "v"(hi));
 }
-// 8 consecutive k-values -> one (hi, lo) fragment pair
-__device__ __forceinline__ void hx_split8(const float (&x)[8], h8& hi, h8& lo) {
+// 8 consecutive k-values, scaled by s -> one (hi, lo) fragment pair
+__device__ __forceinline__ void hx_split8(const float (&x)[8], float s, h8& hi, h8& lo) {
     u32x4 h, l;
     unsigned a, b;
-    hx_split2(x[0], x[1], a, b); h.x = a; l.x = b;
-    hx_split2(x[2], x[3], a, b); h.y = a; l.y = b;
-    hx_split2(x[4], x[5], a, b); h.z = a; l.z = b;
-    hx_split2(x[6], x[7], a, b); h.w = a; l.w = b;
+    hx_split2(x[0], x[1], s, a, b); h.x = a; l.x = b;
+    hx_split2(x[2], x[3], s, a, b); h.y = a; l.y = b;
+    hx_split2(x[4], x[5], s, a, b); h.z = a; l.z = b;
+    hx_split2(x[6], x[7], s, a, b); h.w = a; l.w = b;
     hi = __builtin_bit_cast(h8, h);
     lo = __builtin_bit_cast(h8, l);
 }
-// one value -> (hi | lo << 16), the storage form of split activations in HBM
-__device__ __forceinline__ unsigned hx_pack1(float v) {
-    h2 p;
-    p.x = (_Float16)v;
-    p.y = (_Float16)(v - (float)p.x);
-    return __builtin_bit_cast(unsigned, p);
+// u*t -> (hi | lo << 16), the storage form of split activations in HBM
+__device__ __forceinline__ unsigned hx_pack_prod(float u, float t) {
+    unsigned w;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(w) : "v"(u), "v"(t));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%0 op_sel_hi:[0,0,1]" : "+v"(w) : "v"(u), "v"(t));
+    return w;
 }
 // LDS fragment of unit u (2 KiB: hi then lo) of a stage
 __device__ __forceinline__ h8 hx_frag(const unsigned char* stage, int u, int part, int lane) {

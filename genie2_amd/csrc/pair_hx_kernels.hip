@@ -24,7 +24,23 @@ __device__ __forceinline__ float hx_load(rsrc_t r, int voff, int soff) {
 }
 #define UNI(x) __builtin_amdgcn_readfirstlane(x)
 #define PIPE_FENCE() __builtin_amdgcn_sched_barrier(0)
-#define HX_LDS_BYTES (2 * HX_STAGE_BYTES + 2048)
+#define HX_ZT_BYTES 8192                                   // per-wave row-tile staging (half a tile: 32 rows x 64 channels)
+#define HX_LDS_BYTES (2 * HX_STAGE_BYTES + 2048 + 8 * HX_ZT_BYTES)
+#ifndef HX_ABL
+#define HX_ABL 0          // developer ablation builds (tools/abl_build.sh); 0 in the product
+#endif
+#if HX_ABL & 128          // in-kernel timestamps of wave 0 of work-groups 0, 64, 128, 192 (tools/ts_read.py)
+__device__ unsigned long long g_hx_ts[8][4096];   // [variant * 4 + work-group / 64]
+#define HX_TS_DECL(variant) const bool ts_on = (threadIdx.x >> 6) == 0 && (blockIdx.x & 63) == 0 && blockIdx.x < 256; \
+                   unsigned long long* ts_p = g_hx_ts[(variant) * 4 + (blockIdx.x >> 6)]; int ts_n = 0
+#define HX_TS() do { if (ts_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0 && ts_n < 4096) ts_p[ts_n] = t_; ++ts_n; } } while (0)
+extern "C" int genie_hx_debug_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hx_ts), sizeof(unsigned long long) * 8 * 4096);
+}
+#else
+#define HX_TS_DECL(variant)
+#define HX_TS() do { } while (0)
+#endif
 
 __device__ __forceinline__ void hx_stage_landed() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -62,11 +78,41 @@ __device__ __forceinline__ void hx_norm_split(h8 (&xh)[8], h8 (&xl)[8], float4 (
     const float sc = sx / sqrtf(ss * (1.0f / 128.0f) + GENIE_LN_EPS);
 #pragma unroll
     for (int kc = 0; kc < 8; ++kc) {
-        const float x[8] = {raw[2 * kc].x * sc, raw[2 * kc].y * sc, raw[2 * kc].z * sc, raw[2 * kc].w * sc,
-                            raw[2 * kc + 1].x * sc, raw[2 * kc + 1].y * sc, raw[2 * kc + 1].z * sc, raw[2 * kc + 1].w * sc};
-        hx_split8(x, xh[kc], xl[kc]);
+        const float x[8] = {raw[2 * kc].x, raw[2 * kc].y, raw[2 * kc].z, raw[2 * kc].w,
+                            raw[2 * kc + 1].x, raw[2 * kc + 1].y, raw[2 * kc + 1].z, raw[2 * kc + 1].w};
+        hx_split8(x, sc, xh[kc], xl[kc]);
     }
 }
+
+// Coalesced row-tile loader.  A lane needs 8 consecutive channels of ITS pair row per k-chunk; loading
+// them straight from global memory makes every wave instruction touch 32 different 128-B lines (32 B
+// of each), each line is visited by four instructions, and with 8 waves the 128-KiB tile set thrashes
+// the 32-KiB L1: measured ~10k cycles per tile, 20-40 % of these kernels.  Instead the tile goes
+// through LDS: LDS-DMA (no VGPRs) fetches whole lines -- instruction j = rows 4j..4j+3, 16 lanes x 16 B
+// = 256 contiguous bytes per row -- in two channel halves of 8 KiB, and each lane then reads its row
+// fragments with ds_read_b128.  The 16-B granule g of row r sits in slot g ^ (r & 15) (the swizzle is
+// applied on the GLOBAL side, LDS-DMA writes are lane-linear), which makes those reads conflict free.
+// (j0, nj): which of the half's 8 instructions -- a burst of loads blocks the CU's in-order vector-memory
+// pipe (every wave's stores and weight DMA queue behind the misses), so callers spread them over stages.
+__device__ __forceinline__ void hx_zt_dma(rsrc_t rz, unsigned char* zt, int lane, int soff, int row_stride, int nvalid, int half,
+                                          int j0 = 0, int nj = 8) {
+#pragma unroll
+    for (int j = j0; j < j0 + nj; ++j) {
+        const int r = 4 * j + (lane >> 4);
+        const int voff = min(r, nvalid - 1) * row_stride + (((lane & 15) ^ (r & 15)) << 4);     // rows past the tile: clamped
+        hx_dma(rz, zt + j * 1024, voff, soff + half * 256);
+    }
+}
+__device__ __forceinline__ void hx_zt_read(float4 (&raw)[16], const unsigned char* zt, int pl, int h, int half) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int g = 4 * q + 2 * h;
+        raw[2 * (4 * half + q)] = *reinterpret_cast<const float4*>(zt + pl * 256 + ((g ^ (pl & 15)) << 4));
+        raw[2 * (4 * half + q) + 1] = *reinterpret_cast<const float4*>(zt + pl * 256 + (((g + 1) ^ (pl & 15)) << 4));
+    }
+}
+__device__ __forceinline__ void hx_lds_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void hx_vm_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---------------------------------------------------------------------------------------------
 // Pair transition + end-of-layer mask (modules/pair_transition.py:48-56, pair_transform_net.py:116-117):
@@ -158,8 +204,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_pair_transition_hx
             for (int c = 0; c < 2; ++c) {
                 float x[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = fmaxf(d[8 * c + e] * c1, 0.f);
-                hx_split8(x, ah[c], al[c]);
+                for (int e = 0; e < 8; ++e) x[e] = fmaxf(d[8 * c + e], 0.f);
+                hx_split8(x, c1, ah[c], al[c]);
             }
             {
                 h8 bh = hx_frag(stage, 8, 0, lane), bl = hx_frag(stage, 8, 1, lane);
@@ -202,11 +248,53 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_pair_transition_hx
 // channel-major operand image the contraction reads; a and b are stored already SPLIT
 // (hi | lo << 16 of a S_a), 4 bytes per element as before.
 // ---------------------------------------------------------------------------------------------
+// SOFTWARE PIPELINE: the epilogue of pass s-1 (gate, rescale, split, 16 stores) is issued between
+// the MFMAs of pass s (two accumulator sets ping-pong), one dependent piece per MFMA gap -- a wave's
+// MFMAs are a dependent chain, so whatever sits between them in program order is free, and the
+// stores leave at a steady rate instead of in a burst per stage (unpipelined, the matrix pipe
+// and HBM alternated chip-wide: the kernel took the SUM of its MFMA and its memory time).
+// vmcnt bookkeeping: per stage a wave issues its LDS-DMA pieces for the next stage first, then
+// exactly 16 stores (dropped ones count too), so `s_waitcnt vmcnt(16)` = "the DMA has landed" without
+// waiting for the stores (vector-memory operations retire in order).
+#define HX_PROJ_PIECE_A(EG, r, t)  t = __builtin_amdgcn_exp2f(EG[r] * cg)
+#define HX_PROJ_PIECE_B(EP, r, t, u) do { t = __builtin_amdgcn_rcpf(1.0f + t); u = EP[r] * e_pm; } while (0)
+#if HX_ABL & 2
+#define HX_PROJ_PIECE_C(r, t, u) do { if (u * t == 123.456f) hx_store_u(e_rd, hx_pack_prod(u, t), e_voff, e_so + (((r) & 3) + 8 * ((r) >> 2)) * sstride); } while (0)
+#else
+#define HX_PROJ_PIECE_C(r, t, u) hx_store_u(e_rd, hx_pack_prod(u, t), e_voff, e_so + (((r) & 3) + 8 * ((r) >> 2)) * sstride)
+#endif
+#if HX_ABL & 32
+#define HX_PROJ_REINIT(EP, EG, r) do { } while (0)
+#else
+#define HX_PROJ_REINIT(EP, EG, r) do { EP[r] = sbn[acc_row(r, lane)]; EG[r] = sbn[256 + acc_row(r, lane)]; } while (0)
+#endif
+#define HX_PROJ_STAGE(AP, AG, EP, EG)                                                                              \
+    do {                                                                                                           \
+        const float* sbn = sbias + ((pass + 1) & 7) * 32;   /* EP / EG become the next pass's accumulators */       \
+        if (HX_ABL & 32) { _Pragma("unroll") for (int r = 0; r < 16; ++r) { AP[r] = sbias[pass * 32 + acc_row(r, lane)]; AG[r] = sbias[256 + pass * 32 + acc_row(r, lane)]; } } \
+        h8 ph = hx_frag(stage, 0, 0, lane), pq = hx_frag(stage, 0, 1, lane), gh = hx_frag(stage, 1, 0, lane),     \
+           gq = hx_frag(stage, 1, 1, lane);                                                                        \
+        _Pragma("unroll") for (int kc = 0; kc < 8; ++kc) {                                                         \
+            const int kn = min(kc + 1, 7);                                                                         \
+            const h8 nph = hx_frag(stage, 2 * kn, 0, lane), npq = hx_frag(stage, 2 * kn, 1, lane),                 \
+                     ngh = hx_frag(stage, 2 * kn + 1, 0, lane), ngq = hx_frag(stage, 2 * kn + 1, 1, lane);         \
+            float t0, t1, u0, u1;                                                                                  \
+            PIPE_FENCE(); MFH(pq, zh[kc], AP); PIPE_FENCE(); HX_PROJ_PIECE_A(EG, 2 * kc, t0);                      \
+            PIPE_FENCE(); MFH(ph, zl[kc], AP); PIPE_FENCE(); HX_PROJ_PIECE_B(EP, 2 * kc, t0, u0);                  \
+            PIPE_FENCE(); MFH(ph, zh[kc], AP); PIPE_FENCE(); HX_PROJ_PIECE_C(2 * kc, t0, u0); HX_PROJ_REINIT(EP, EG, 2 * kc); \
+            PIPE_FENCE(); MFH(gq, zh[kc], AG); PIPE_FENCE(); HX_PROJ_PIECE_A(EG, 2 * kc + 1, t1);                  \
+            PIPE_FENCE(); MFH(gh, zl[kc], AG); PIPE_FENCE(); HX_PROJ_PIECE_B(EP, 2 * kc + 1, t1, u1);              \
+            PIPE_FENCE(); MFH(gh, zh[kc], AG); PIPE_FENCE(); HX_PROJ_PIECE_C(2 * kc + 1, t1, u1); HX_PROJ_REINIT(EP, EG, 2 * kc + 1); \
+            PIPE_FENCE();                                                                                          \
+            ph = nph; pq = npq; gh = ngh; gq = ngq;                                                                \
+        }                                                                                                          \
+    } while (0)
+
 template <bool OUTGOING, int NW>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_proj_hx(
     const float* __restrict__ z, const float* __restrict__ rmask, const unsigned char* __restrict__ wimg,
     const float* __restrict__ bias, unsigned* __restrict__ acm, unsigned* __restrict__ bcm, int N, int NP, int n_wtiles,
-    unsigned cm_bytes, float sx, float cpa, float cpb, float cg) {
+    unsigned cm_bytes, unsigned z_bytes, float sx, float cpa, float cpb, float cg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
     float* sbias = reinterpret_cast<float*>(smb + 2 * HX_STAGE_BYTES);      // [512]
     const int lane = threadIdx.x & 63, wave = UNI(threadIdx.x >> 6);
@@ -225,73 +313,105 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_proj_hx(
             hx_dma(rw, smb + buf * HX_STAGE_BYTES + p * 1024, lane16, pass * HX_STAGE_BYTES + p * 1024);
         }
     };
-    auto row_ptr = [&](int tile) {                        // this lane's row of wave-tile NW tile + wave (clamped: always readable)
+    unsigned char* zt = smb + 2 * HX_STAGE_BYTES + 2048 + wave * HX_ZT_BYTES;
+    const rsrc_t rz = hx_rsrc(z, z_bytes);
+    const int zstride = OUTGOING ? 512 : N * 512;         // bytes between consecutive pairs of a tile
+    auto tile_geom = [&](int tile, int& soff, int& nv) {  // wave-tile NW tile + wave (clamped): byte offset of its first row, valid rows
         const int wt = min(tile * NW + wave, n_wtiles - 1);
         const int st = wt % ntile, line = (wt / ntile) % N, b = wt / (ntile * N);
-        const int pr = min(pl, min(32, N - st * 32) - 1);
-        return OUTGOING ? z + (((size_t)b * N + line) * N + st * 32 + pr) * 128
-                        : z + (((size_t)b * N + st * 32 + pr) * N + line) * 128;
+        nv = min(32, N - st * 32);
+        soff = OUTGOING ? ((b * N + line) * N + st * 32) * 512 : ((b * N + st * 32) * N + line) * 512;
     };
     int tile = blockIdx.x;
+    HX_TS_DECL(OUTGOING ? 1 : 0);
     issue(0, 0);
     for (int u = threadIdx.x; u < 512; u += NW * 64) sbias[u] = bias[u];
     __syncthreads();
+    f32x16 apA, agA, apB, agB;                            // set A: even passes, set B: odd passes
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { apB[r] = 0.f; agB[r] = 0.f; apA[r] = sbias[acc_row(r, lane)]; agA[r] = sbias[256 + acc_row(r, lane)]; }
+    h8 zh[8], zl[8];
+    float4 raw[16];
+    int n_soff, n_nv;
+    tile_geom(tile, n_soff, n_nv);
+    hx_zt_dma(rz, zt, lane, n_soff, zstride, n_nv, 0); hx_vm_done(); hx_zt_read(raw, zt, pl, h, 0); hx_lds_done();
+    hx_zt_dma(rz, zt, lane, n_soff, zstride, n_nv, 1); hx_vm_done(); hx_zt_read(raw, zt, pl, h, 1);
+    int p_voff = 0x7FFFFFF0, p_so = 0;                    // epilogue state of the previous tile's pass 7 (none yet: stores dropped)
+    float p_pm = 0.f;
 #pragma unroll 1
     for (; tile < n_tiles; tile += gridDim.x) {
         const int wt_raw = tile * NW + wave;
         const bool act = wt_raw < n_wtiles;
         const int wt = act ? wt_raw : n_wtiles - 1;      // idle waves shadow the last tile (stores dropped)
         const int st = wt % ntile, line = (wt / ntile) % N, b = wt / (ntile * N);
-        const int t0 = st * 32;
-        const int nvalid = act ? min(32, N - t0) : 0;
-        const float msk = (pl < nvalid) ? rmask[b * N + line] * rmask[b * N + t0 + pl] : 0.f;
+        const int t0i = st * 32;
+        const int nvalid = act ? min(32, N - t0i) : 0;
+        const float msk = (pl < nvalid) ? rmask[b * N + line] * rmask[b * N + t0i + pl] : 0.f;
         const float ma = msk * cpa, mb = msk * cpb;
         // channel-major store: element ((b*128 + ch)*NP + line)*NP + t0 + pl, ch = 32 (pass & 3) + row
         const int voff = (pl < nvalid) ? (4 * h * NP * NP + pl) * 4 : 0x7FFFFFF0;   // out-of-range offset: store dropped
-        const int sbase = ((b * 128 * NP + line) * NP + t0) * 4;
+        const int sbase = ((b * 128 * NP + line) * NP + t0i) * 4;
         const bool more = tile + (int)gridDim.x < n_tiles;
-        h8 zh[8], zl[8];
-        {
-            float4 raw[16];
-            hx_load_rows(raw, row_ptr(tile), h);
-            hx_norm_split(zh, zl, raw, sx);
-        }
+        HX_TS();
+        hx_norm_split(zh, zl, raw, sx);
 #pragma unroll 1
-        for (int pass = 0; pass < 8; ++pass) {
-            if (pass + 1 < 8) issue(pass + 1, (pass + 1) & 1);
-            else if (more) issue(0, 0);
-            const unsigned char* stage = smb + (pass & 1) * HX_STAGE_BYTES;
-            const float* sb = sbias + pass * 32;
-            f32x16 ap, ag;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { ap[r] = sb[acc_row(r, lane)]; ag[r] = sb[256 + acc_row(r, lane)]; }
-            {
-                h8 ph = hx_frag(stage, 0, 0, lane), pq = hx_frag(stage, 0, 1, lane), gh = hx_frag(stage, 1, 0, lane),
-                   gq = hx_frag(stage, 1, 1, lane);
-#pragma unroll
-                for (int kc = 0; kc < 8; ++kc) {
-                    const int kn = min(kc + 1, 7);
-                    const h8 nph = hx_frag(stage, 2 * kn, 0, lane), npq = hx_frag(stage, 2 * kn, 1, lane),
-                             ngh = hx_frag(stage, 2 * kn + 1, 0, lane), ngq = hx_frag(stage, 2 * kn + 1, 1, lane);
-                    PIPE_FENCE();
-                    MFH3(ph, pq, zh[kc], zl[kc], ap);
-                    MFH3(gh, gq, zh[kc], zl[kc], ag);
-                    PIPE_FENCE();
-                    ph = nph; pq = npq; gh = ngh; gq = ngq;
+        for (int pp = 0; pp < 4; ++pp) {
+            {   // even pass 2pp -> set A; epilogue of pass 2pp - 1 (set B; for pp = 0 the previous tile's pass 7)
+                const int pass = 2 * pp;
+                HX_TS();
+                if (more) {                               // next tile's rows, two DMA instructions per stage; first half -> raw at pass 4
+                    if (pp == 0) tile_geom(tile + gridDim.x, n_soff, n_nv);
+                    if (pp == 2) { hx_zt_read(raw, zt, pl, h, 0); hx_lds_done(); }
+                    if (pp < 2) hx_zt_dma(rz, zt, lane, n_soff, zstride, n_nv, 0, 4 * pp, 2);
+                    else        hx_zt_dma(rz, zt, lane, n_soff, zstride, n_nv, 1, 4 * (pp - 2), 2);
                 }
+                issue(pass + 1, 1);
+                const unsigned char* stage = smb;
+                const rsrc_t e_rd = (pp == 0 || pp > 2) ? rb : ra;
+                const int e_voff = pp == 0 ? p_voff : voff;
+                const int e_so = pp == 0 ? p_so : sbase + ((pass - 1) & 3) * 32 * sstride;
+                const float e_pm = pp == 0 ? p_pm : (pp > 2 ? mb : ma);
+                HX_PROJ_STAGE(apA, agA, apB, agB);
+                HX_TS();
+                if (!(HX_ABL & 8)) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); HX_TS(); hx_stage_barrier(); }
+                HX_TS();
             }
-            hx_stage_landed();
-            const rsrc_t rd = pass < 4 ? ra : rb;
-            const float pm = pass < 4 ? ma : mb;
-            const int so = sbase + (pass & 3) * 32 * sstride;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {   // register r holds channel rows (r&3) + 8(r>>2) [+4 for the upper half-wave: in voff]
-                const float pv = ap[r], gv = ag[r];
-                const float v = pv * pm * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gv * cg));
-                hx_store_u(rd, hx_pack1(v), voff, so + ((r & 3) + 8 * (r >> 2)) * sstride);
+            {   // odd pass 2pp + 1 -> set B; epilogue of pass 2pp (set A)
+                const int pass = 2 * pp + 1;
+                HX_TS();
+                if (more) {
+                    if (pp < 2) hx_zt_dma(rz, zt, lane, n_soff, zstride, n_nv, 0, 4 * pp + 2, 2);
+                    else        hx_zt_dma(rz, zt, lane, n_soff, zstride, n_nv, 1, 4 * (pp - 2) + 2, 2);
+                }
+                if (pp < 3) issue(pass + 1, 0);
+                else if (more) issue(0, 0);
+                const unsigned char* stage = smb + HX_STAGE_BYTES;
+                const rsrc_t e_rd = pp < 2 ? ra : rb;
+                const int e_voff = voff;
+                const int e_so = sbase + ((pass - 1) & 3) * 32 * sstride;
+                const float e_pm = pp < 2 ? ma : mb;
+                HX_PROJ_STAGE(apB, agB, apA, agA);
+                HX_TS();
+                if (!(HX_ABL & 8)) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); HX_TS(); hx_stage_barrier(); }
+                HX_TS();
             }
-            hx_stage_barrier();
         }
+        p_voff = voff; p_so = sbase + 3 * 32 * sstride; p_pm = mb;
+        if (more) hx_zt_read(raw, zt, pl, h, 1);          // second half: read at the tile boundary (register pressure)
+    }
+    {   // drain: epilogue of the last pass 7 (set B)
+        const rsrc_t e_rd = rb;
+        const int e_voff = p_voff, e_so = p_so;
+        const float e_pm = p_pm;
+        float t[16], u[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            HX_PROJ_PIECE_A(agB, r, t[r]);
+            HX_PROJ_PIECE_B(apB, r, t[r], u[r]);
+        }
+        PIPE_FENCE();           // (the packs are asm: keep them clear of the v_rcp results' forwarding window)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) HX_PROJ_PIECE_C(r, t[r], u[r]);
     }
 }
 
@@ -583,11 +703,7 @@ static int hx_num_cu() {
     if (!g_hx_cu) { int dev = 0; hipDeviceProp_t pr; (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&pr, dev); g_hx_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     return g_hx_cu;
 }
-static int g_hx_nw = 0;      // waves per work-group: 8 (one WG per CU) or 4 (two)
-static int hx_nw() {
-    if (!g_hx_nw) { const char* e = getenv("GENIE_HX_WAVES"); g_hx_nw = (e && atoi(e) == 4) ? 4 : 8; }
-    return g_hx_nw;
-}
+static int hx_nw() { return 8; }   // waves per work-group (one work-group per CU: 130 KiB of LDS)
 static unsigned hx_grid(long long n_tiles, int nw) {
     const long long cap = (nw == 8 ? 1LL : 2LL) * hx_num_cu();
     return (unsigned)(n_tiles < cap ? n_tiles : cap);
@@ -598,12 +714,8 @@ void launch_pair_transition_hx(genie_ctx* h, hipStream_t st, const PairLayerW& w
     const long long n_wt = (M + 31) / 32;
     const int n_hb = h->d.pair_transition_n * 4;
     const HxTransW& x = w.hx_pt;
-    if (hx_nw() == 8)
-        hipLaunchKernelGGL(k_pair_transition_hx<8>, dim3(hx_grid((n_wt + 7) / 8, 8)), dim3(512), HX_LDS_BYTES, st, h->p, h->rmaskf,
-                           x.img, x.b1s, x.b2s, h->N, M, n_hb, x.sx, x.c1, x.c2);
-    else
-        hipLaunchKernelGGL(k_pair_transition_hx<4>, dim3(hx_grid((n_wt + 3) / 4, 4)), dim3(256), HX_LDS_BYTES, st, h->p, h->rmaskf,
-                           x.img, x.b1s, x.b2s, h->N, M, n_hb, x.sx, x.c1, x.c2);
+    hipLaunchKernelGGL(k_pair_transition_hx<8>, dim3(hx_grid((n_wt + 7) / 8, 8)), dim3(512), HX_LDS_BYTES, st, h->p, h->rmaskf,
+                       x.img, x.b1s, x.b2s, h->N, M, n_hb, x.sx, x.c1, x.c2);
 }
 
 void launch_trimul_hx(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgoing) {
@@ -614,13 +726,14 @@ void launch_trimul_hx(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgo
     const unsigned cm_bytes = (unsigned)((size_t)h->B * 128 * NP * NP * 4);
     unsigned* acm = reinterpret_cast<unsigned*>(h->acm);
     unsigned* bcm = reinterpret_cast<unsigned*>(h->bcm);
+    const unsigned z_bytes = (unsigned)((size_t)h->B * N * N * 512);
     {
         ProfScope ps(h, st, KC_TRIMUL_PROJ);
         const dim3 grid(hx_grid((n_wt + nw - 1) / nw, nw)), block(nw * 64);
 #define HX_PROJ(OUT, NWV) hipLaunchKernelGGL((k_trimul_proj_hx<OUT, NWV>), grid, block, HX_LDS_BYTES, st, h->p, h->rmaskf, x.img_proj, \
-                                             x.bias_proj, acm, bcm, N, NP, n_wt, cm_bytes, x.sx, x.cpa, x.cpb, x.cg)
-        if (outgoing) { if (nw == 8) HX_PROJ(true, 8); else HX_PROJ(true, 4); }
-        else          { if (nw == 8) HX_PROJ(false, 8); else HX_PROJ(false, 4); }
+                                             x.bias_proj, acm, bcm, N, NP, n_wt, cm_bytes, z_bytes, x.sx, x.cpa, x.cpb, x.cg)
+        if (outgoing) HX_PROJ(true, 8);
+        else HX_PROJ(false, 8);
 #undef HX_PROJ
     }
     {
@@ -641,21 +754,15 @@ void launch_trimul_hx(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgo
     }
     {
         ProfScope ps(h, st, KC_TRIMUL_OUT);
-        const unsigned z_bytes = (unsigned)((size_t)h->B * N * N * 512);
-        if (nw == 8)
-            hipLaunchKernelGGL(k_trimul_out_hx<8>, dim3(hx_grid((n_wt + 7) / 8, 8)), dim3(512), HX_LDS_BYTES, st, h->p, h->xcm, x.img_out,
-                               x.bgs, x.bzs, N, NP, n_wt, cm_bytes, z_bytes, x.sx, x.cgo, x.cz);
-        else
-            hipLaunchKernelGGL(k_trimul_out_hx<4>, dim3(hx_grid((n_wt + 3) / 4, 4)), dim3(256), HX_LDS_BYTES, st, h->p, h->xcm, x.img_out,
-                               x.bgs, x.bzs, N, NP, n_wt, cm_bytes, z_bytes, x.sx, x.cgo, x.cz);
+        hipLaunchKernelGGL(k_trimul_out_hx<8>, dim3(hx_grid((n_wt + 7) / 8, 8)), dim3(512), HX_LDS_BYTES, st, h->p, h->xcm, x.img_out,
+                           x.bgs, x.bzs, N, NP, n_wt, cm_bytes, z_bytes, x.sx, x.cgo, x.cz);
     }
 }
 
 void pair_hx_kernels_init() {
 #define HX_ATTR(k) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, HX_LDS_BYTES)
-    HX_ATTR((k_trimul_proj_hx<true, 8>)); HX_ATTR((k_trimul_proj_hx<true, 4>)); HX_ATTR((k_trimul_proj_hx<false, 8>)); HX_ATTR((k_trimul_proj_hx<false, 4>));
-    HX_ATTR(k_trimul_out_hx<8>); HX_ATTR(k_trimul_out_hx<4>);
+    HX_ATTR((k_trimul_proj_hx<true, 8>)); HX_ATTR((k_trimul_proj_hx<false, 8>));
+    HX_ATTR(k_trimul_out_hx<8>);
 #undef HX_ATTR
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_transition_hx<8>), hipFuncAttributeMaxDynamicSharedMemorySize, HX_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_transition_hx<4>), hipFuncAttributeMaxDynamicSharedMemorySize, HX_LDS_BYTES);
 }

@@ -21,7 +21,7 @@ def _ptr(t):
 
 
 class GenieEngine:
-    def __init__(self, dims, state_dict, device='cuda:0', n_pos=None, n_chain=None):
+    def __init__(self, dims, state_dict, device='cuda:0', n_pos=None, n_chain=None, math=None):
         self.lib = capi.load_library()
         self.device = torch.device(device)
         if self.device.type != 'cuda':
@@ -46,6 +46,18 @@ class GenieEngine:
         capi.check(self._h, self.lib.genie_set_tables(self._h, _ptr(pos), self.n_pos, _ptr(chn), self.n_chain,
                                                       _ptr(tt), _ptr(sb)), 'genie_set_tables')
         self.B = self.N = None
+        if math is not None:
+            self.set_math(math)
+
+    MATH_MODES = {'f32': 0, 'hx': 1}
+
+    def set_math(self, mode):
+        """'hx' (default): pair-stack GEMMs as three f16 MFMAs on split operands; 'f32': exact f32 MFMA."""
+        capi.check(self._h, self.lib.genie_set_math(self._h, self.MATH_MODES[mode]), 'genie_set_math')
+
+    @property
+    def math(self):
+        return 'hx' if self.lib.genie_get_math(self._h) == 1 else 'f32'
 
     def close(self):
         if getattr(self, '_h', None):

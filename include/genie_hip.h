@@ -151,6 +151,21 @@ int genie_sample_loop(genie_handle_t h, genie_stream_t stream, float scale,
                       int first_step, int last_step,
                       float* trans_io, float* rots_io, float* record);
 
+/* ---- arithmetic -------------------------------------------------------- */
+
+/* How the pair-stack GEMMs (triangle multiplication, pair transition: 95 % of the FLOPs of
+ * genie/model/model.py:125-192) are carried out.  Both give f32 results to the stated tolerance;
+ * the reference computes them with f32 torch.matmul / nn.Linear.
+ *   GENIE_MATH_HX  (default) every f32 operand is split in two f16 halves (22 significand bits) and
+ *                  a product is three f16 MFMAs accumulated in f32 (csrc/hx.h);
+ *   GENIE_MATH_F32 exact f32 MFMA (v_mfma_f32_32x32x2_f32), 1/16 of the matrix rate.
+ * May be switched at any time between calls (both weight images are kept).  The environment
+ * variable GENIE_MATH=f32|hx sets the initial mode of new handles. */
+#define GENIE_MATH_F32 0
+#define GENIE_MATH_HX 1
+int genie_set_math(genie_handle_t h, int mode);
+int genie_get_math(genie_handle_t h);
+
 /* ---- measurement ------------------------------------------------------- */
 
 /* Per-kernel-class HIP-event timing on the launch stream (bench.py roofline

@@ -70,8 +70,21 @@ def test_p_sample_matches_oracle(base_engine):
 
 
 # --------------------------------------------------------------- single calls vs reference goldens
+MATH_MODES = ['hx', 'f32']       # split-f16 MFMA (default) / exact f32 MFMA: same tolerances for both
+
+
+@pytest.fixture
+def math_engine(request, base_engine):
+    base_engine.set_math(request.param)
+    assert base_engine.math == request.param
+    yield base_engine
+    base_engine.set_math('hx')
+
+
+@pytest.mark.parametrize('math_engine', MATH_MODES, indirect=True)
 @pytest.mark.parametrize('case', CALL_CASES)
-def test_denoiser_call_matches_reference_golden(case, base_engine):
+def test_denoiser_call_matches_reference_golden(case, math_engine):
+    base_engine = math_engine
     g = load_golden('call_' + case)
     f = golden_features(g)
     B, N = f['residue_mask'].shape
@@ -94,13 +107,14 @@ def test_denoiser_call_matches_reference_golden(case, base_engine):
     assert mdiff(out['trans_out'].cpu() * m, t(g['trans_out']) * m) <= 1e-4 * max(1.0, float(np.abs(g['trans_out']).max()))
 
 
-def test_trajectory_matches_reference_golden(base_weights):
+@pytest.mark.parametrize('math', MATH_MODES)
+def test_trajectory_matches_reference_golden(base_weights, math):
     """Config 1 (N=50, T=100, batch 1, scale 0.6): the reference's own
     UnconditionalSampler._sample, same noise, eigh signs supplied."""
     from genie2_amd.engine import GenieEngine
     g = load_golden('trajectory_n50_t100')
     dims = dict(O.BASE_DIMS, n_timestep=100)
-    eng = GenieEngine(dims, base_weights, 'cuda:0')
+    eng = GenieEngine(dims, base_weights, 'cuda:0', math=math)
     eng.bind_features(O.empty_features([50]))
     final, _, rec = eng.sample_loop(t(g['noise']), float(g['scale']), quat_codes=t(g['quat_codes']), record=True)
     ref = t(g['final'])
@@ -138,8 +152,8 @@ def _case(name, g):
 
 
 @pytest.mark.parametrize('name', ['n70_b3_ragged', 'n130_b1', 'n20_multichain_motif', 'n2_tiny'])
-@pytest.mark.parametrize('rescale', [1.0, 2.0])
-def test_denoiser_matches_oracle_small_dims(name, rescale):
+@pytest.mark.parametrize('rescale,math', [(1.0, 'hx'), (2.0, 'hx'), (1.0, 'f32')])
+def test_denoiser_matches_oracle_small_dims(name, rescale, math):
     from genie2_amd.engine import GenieEngine
     dims = O.small_dims(rescale=rescale)
     sd = O.synthetic_state_dict(dims, seed=3)
@@ -152,7 +166,7 @@ def test_denoiser_matches_oracle_small_dims(name, rescale):
     ts = torch.randint(1, dims['n_timestep'] + 1, (B,), generator=g).int()
     taps = {}
     ref = O.denoiser_forward(sd, dims, rots, trans, ts, f, 'closed', None, taps)
-    eng = GenieEngine(dims, sd, 'cuda:0')
+    eng = GenieEngine(dims, sd, 'cuda:0', math=math)
     eng.bind_features(f)
     out = eng.denoise(trans, rots, ts, None, taps=('s', 'p', 'p_init'))
     m = fr['residue_mask'].unsqueeze(-1).float()
@@ -164,6 +178,36 @@ def test_denoiser_matches_oracle_small_dims(name, rescale):
 
 
 # --------------------------------------------------------------- full size (BASELINE config 2 shape)
+@pytest.mark.parametrize('scale', [1e-3, 1.0, 40.0])
+def test_hx_operand_scaling_follows_the_weights(scale):
+    """The split-f16 path derives its power-of-two operand scales from the weights at load time
+    (hx.h): pair-stack weights 1000x smaller or 40x larger must neither flush nor overflow."""
+    from genie2_amd.engine import GenieEngine
+    dims = O.small_dims()
+    sd = O.synthetic_state_dict(dims, seed=5)
+    for k in sd:
+        if k.startswith('pair_transform_net') and k.endswith('weight') and 'layer_norm' not in k and sd[k].dim() == 2:
+            sd[k] = sd[k] * scale
+    g = torch.Generator().manual_seed(11)
+    f = O.empty_features([48, 40])
+    trans = 2.5 * torch.randn(2, 48, 3, generator=g)
+    fr = O.prepare_features(f)
+    rots = O.compute_frenet_frames(trans, fr['chain_index'], fr['residue_mask'])
+    ts = torch.tensor([60, 3], dtype=torch.int32)
+    ref = O.denoiser_forward(sd, dims, rots, trans, ts, f, 'closed')
+    assert torch.isfinite(ref['p']).all()
+    eng = GenieEngine(dims, sd, 'cuda:0', math='hx')
+    eng.bind_features(f)
+    out = eng.denoise(trans, rots, ts, None, taps=('p',))
+    m = fr['residue_mask'].unsqueeze(-1).float()
+    assert mdiff(out['p'], ref['p']) <= 1e-4 * max(1.0, float(ref['p'].abs().max()))
+    assert mdiff(out['z'].cpu() * m, ref['z'] * m) <= 1e-4 * max(1.0, float(ref['z'].abs().max()))
+    eng.set_math('f32')
+    z32 = eng.denoise(trans, rots, ts, None)['z'].cpu()
+    assert mdiff(z32 * m, ref['z'] * m) <= 1e-4 * max(1.0, float(ref['z'].abs().max()))
+    eng.close()
+
+
 def test_full_size_n256_matches_oracle_and_batches_are_independent(base_engine, base_weights):
     """N=256 (the metric's length): batch entry 0 against the oracle directly
     (one structure is ~3 s of CPU), then size-independent properties at batch 8:

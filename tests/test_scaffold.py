@@ -85,12 +85,14 @@ def test_scaffold_cli_flags_and_tasks(tmp_path):
 
 
 @pytest.mark.gpu
-def test_scaffold_sampler_matches_reference_golden(tmp_path, base_weights):
+@pytest.mark.parametrize('math', ['hx', 'f32'])
+def test_scaffold_sampler_matches_reference_golden(tmp_path, base_weights, math, monkeypatch):
     """genie.sampler.scaffold.ScaffoldSampler over the HIP engine against the reference's own
     ScaffoldSampler._sample run (same np/torch streams via explicit noise + recorded quaternion signs)."""
     from genie.config import Config
     from genie.sampler.scaffold import ScaffoldSampler
     from genie2_amd.diffusion import Genie
+    monkeypatch.setenv('GENIE_MATH', math)          # initial arithmetic of the engine the façade creates
     g = load_golden('trajectory_scaffold_t20')
     cfg = Config()
     cfg.diffusion['n_timestep'] = 20
