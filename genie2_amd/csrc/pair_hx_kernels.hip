@@ -4,6 +4,7 @@
 // 16x less matrix-pipe time per f32 FLOP than v_mfma_f32_32x32x2_f32 x 3 products = 5.3x, and the
 // VALU work (LayerNorm, splits, gates) now overlaps the MFMAs instead of competing for the FP32 lanes.
 #include <stdlib.h>
+#include <type_traits>
 #include "hx.h"
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -29,13 +30,13 @@ __device__ __forceinline__ float hx_load(rsrc_t r, int voff, int soff) {
 #ifndef HX_ABL
 #define HX_ABL 0          // developer ablation builds (tools/abl_build.sh); 0 in the product
 #endif
-#if HX_ABL & 128          // in-kernel timestamps of wave 0 of work-groups 0, 64, 128, 192 (tools/ts_read.py)
-__device__ unsigned long long g_hx_ts[8][4096];   // [variant * 4 + work-group / 64]
-#define HX_TS_DECL(variant) const bool ts_on = (threadIdx.x >> 6) == 0 && (blockIdx.x & 63) == 0 && blockIdx.x < 256; \
-                   unsigned long long* ts_p = g_hx_ts[(variant) * 4 + (blockIdx.x >> 6)]; int ts_n = 0
+#if HX_ABL & 128          // in-kernel timestamps of every wave of work-group 0 (tools/ts_read.py)
+__device__ unsigned long long g_hx_ts[24][4096];   // [variant * 8 + wave]
+#define HX_TS_DECL(variant) const bool ts_on = blockIdx.x == 0; \
+                   unsigned long long* ts_p = g_hx_ts[(variant) * 8 + (threadIdx.x >> 6)]; int ts_n = 0
 #define HX_TS() do { if (ts_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0 && ts_n < 4096) ts_p[ts_n] = t_; ++ts_n; } } while (0)
 extern "C" int genie_hx_debug_read(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hx_ts), sizeof(unsigned long long) * 8 * 4096);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hx_ts), sizeof(unsigned long long) * 24 * 4096);
 }
 #else
 #define HX_TS_DECL(variant)
@@ -144,15 +145,32 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_pair_transition_hx
             hx_dma(rw, smb + buf * HX_STAGE_BYTES + p * 1024, lane16, hb * HX_STAGE_BYTES + p * 1024);
         }
     };
-    auto row_ptr = [&](int tile) {                // this lane's row of wave-tile NW tile + wave (clamped: always readable)
+    unsigned char* zt = smb + 2 * HX_STAGE_BYTES + 2048 + wave * HX_ZT_BYTES;
+    auto tile_geom = [&](int tile, int& soff, int& nv) {      // wave-tile NW tile + wave (clamped): first row (bytes), valid rows
         const long long r0 = (long long)min(tile * NW + wave, n_wt - 1) * 32;
-        return z + (r0 + min(pl, (int)min((long long)32, M - r0) - 1)) * 128;
+        nv = (int)min((long long)32, M - r0);
+        soff = (int)(r0 * 512);
     };
+    // next tile's rows: half 0 requested in stage hq0, moved to registers (and half 1 requested) in stage hq1, half 1 read at
+    // the tile boundary; with fewer than 2 stages per tile the tile is loaded synchronously instead
+    const bool prefetch = n_hb >= 2;
+    const int hq0 = max(0, n_hb / 2 - 2), hq1 = min(n_hb - 1, hq0 + 4);
     int tile = blockIdx.x;
+    HX_TS_DECL(2);
     issue(0, 0);
     for (int u = threadIdx.x; u < n_hb * 32; u += NW * 64) sb1[u] = b1s[u];
     const float cb0 = b2s[pl], cb1 = b2s[32 + pl], cb2 = b2s[64 + pl], cb3 = b2s[96 + pl];
+    float4 raw[16];
+    int n_soff, n_nv;
+    auto load_sync = [&](int t) {
+        tile_geom(t, n_soff, n_nv);
+        hx_zt_dma(rz, zt, lane, n_soff, 512, n_nv, 0); hx_vm_done(); hx_zt_read(raw, zt, pl, h, 0); hx_lds_done();
+        hx_zt_dma(rz, zt, lane, n_soff, 512, n_nv, 1); hx_vm_done(); hx_zt_read(raw, zt, pl, h, 1);
+    };
+    load_sync(tile);
     __syncthreads();
+    h8 zh[8], zl[8];
+    float zres[4][16];
 #pragma unroll 1
     for (; tile < n_tiles; tile += gridDim.x) {
         const int wt_raw = tile * NW + wave;
@@ -167,12 +185,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_pair_transition_hx
             const int rem = (int)(idx - (long long)bb * N * N);
             m_own = rmask[bb * N + rem / N] * rmask[bb * N + rem % N];
         }
-        h8 zh[8], zl[8];
-        {
-            float4 raw[16];
-            hx_load_rows(raw, row_ptr(tile), h);
-            hx_norm_split(zh, zl, raw, sx);
-        }
+        hx_norm_split(zh, zl, raw, sx);
         f32x16 o[4];
         {
             float e0 = cb0, e1 = cb1, e2 = cb2, e3 = cb3;
@@ -180,9 +193,17 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_pair_transition_hx
 #pragma unroll
             for (int r = 0; r < 16; ++r) { o[0][r] = e0; o[1][r] = e1; o[2][r] = e2; o[3][r] = e3; }
         }
-#pragma unroll 1
-        for (int hb = 0; hb < n_hb; ++hb) {
-            if (hb + 1 < n_hb) issue(hb + 1, (hb + 1) & 1);
+        const rsrc_t rzz = act ? rz : rnull;
+        const int voff = (4 * h * 128 + pl) * 4;
+        const int srow0 = (int)(row0 * 512);
+        auto stage_body = [&](int hb, auto last_tag) {
+            constexpr bool LAST = decltype(last_tag)::value;
+            HX_TS();
+            if (more && prefetch) {
+                if (hb == hq0) { tile_geom(tile + gridDim.x, n_soff, n_nv); hx_zt_dma(rz, zt, lane, n_soff, 512, n_nv, 0); }
+                if (hb == hq1) { hx_zt_read(raw, zt, pl, h, 0); hx_lds_done(); hx_zt_dma(rz, zt, lane, n_soff, 512, n_nv, 1); }
+            }
+            if (!LAST) issue(hb + 1, (hb + 1) & 1);
             else if (more) issue(0, 0);
             const unsigned char* stage = smb + (hb & 1) * HX_STAGE_BYTES;
             f32x16 d;
@@ -197,6 +218,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_pair_transition_hx
                     MFH3(wh, wl, zh[kc], zl[kc], d);
                     PIPE_FENCE();
                     wh = nh; wl = nl;
+                }
+            }
+            HX_TS();
+            if (LAST) {     // zh / zl are dead from here on: the first half of the residual rows is fetched while the last GEMM runs
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int so = srow0 + ((r & 3) + 8 * (r >> 2)) * 512;
+                    zres[0][r] = hx_load(rzz, voff, so); zres[1][r] = hx_load(rzz, voff, so + 128);
+                    zres[2][r] = hx_load(rzz, voff, so + 256); zres[3][r] = hx_load(rzz, voff, so + 384);
                 }
             }
             h8 ah[2], al[2];
@@ -218,24 +248,34 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_pair_transition_hx
                     bh = nh; bl = nl;
                 }
             }
+            HX_TS();
             __syncthreads();
+            HX_TS();
+        };
+#pragma unroll 1
+        for (int hb = 0; hb + 1 < n_hb; ++hb) stage_body(hb, std::false_type{});
+        stage_body(n_hb - 1, std::true_type{});
+        // epilogue: row t = acc_row(r, lane) of the tile, channel 32 ob + pl; second half of the residual rows requested first
+#pragma unroll
+        for (int r = 8; r < 16; ++r) {
+            const int so = srow0 + ((r & 3) + 8 * (r >> 2)) * 512;
+            zres[0][r] = hx_load(rzz, voff, so); zres[1][r] = hx_load(rzz, voff, so + 128);
+            zres[2][r] = hx_load(rzz, voff, so + 256); zres[3][r] = hx_load(rzz, voff, so + 384);
         }
-        // epilogue: row t = acc_row(r, lane) of the tile, channel 32 ob + pl
-        const rsrc_t rzz = act ? rz : rnull;
-        const int voff = (4 * h * 128 + pl) * 4;
-        const int srow0 = (int)(row0 * 512);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rc = (r & 3) + 8 * (r >> 2);
             const float m = __shfl(m_own, rc + 4 * h);
             const int so = srow0 + rc * 512;
-            const float z0 = hx_load(rzz, voff, so), z1 = hx_load(rzz, voff, so + 128), z2 = hx_load(rzz, voff, so + 256),
-                        z3 = hx_load(rzz, voff, so + 384);
             const float v0 = o[0][r], v1 = o[1][r], v2 = o[2][r], v3 = o[3][r];
-            hx_store(rzz, fmaf(v0, c2, z0) * m, voff, so);
-            hx_store(rzz, fmaf(v1, c2, z1) * m, voff, so + 128);
-            hx_store(rzz, fmaf(v2, c2, z2) * m, voff, so + 256);
-            hx_store(rzz, fmaf(v3, c2, z3) * m, voff, so + 384);
+            hx_store(rzz, fmaf(v0, c2, zres[0][r]) * m, voff, so);
+            hx_store(rzz, fmaf(v1, c2, zres[1][r]) * m, voff, so + 128);
+            hx_store(rzz, fmaf(v2, c2, zres[2][r]) * m, voff, so + 256);
+            hx_store(rzz, fmaf(v3, c2, zres[3][r]) * m, voff, so + 384);
+        }
+        if (more) {
+            if (prefetch) hx_zt_read(raw, zt, pl, h, 1);
+            else load_sync(tile + gridDim.x);
         }
     }
 }
@@ -256,14 +296,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_pair_transition_hx
 // vmcnt bookkeeping: per stage a wave issues its LDS-DMA pieces for the next stage first, then
 // exactly 16 stores (dropped ones count too), so `s_waitcnt vmcnt(16)` = "the DMA has landed" without
 // waiting for the stores (vector-memory operations retire in order).
+#if HX_ABL & 512
+#define HX_PROJ_PIECE_A(EG, r, t)  t = EG[r] * cg
+#define HX_PROJ_PIECE_B(EP, r, t, u) do { t = 1.0f + t; u = EP[r] * e_pm; } while (0)
+#else
 #define HX_PROJ_PIECE_A(EG, r, t)  t = __builtin_amdgcn_exp2f(EG[r] * cg)
 #define HX_PROJ_PIECE_B(EP, r, t, u) do { t = __builtin_amdgcn_rcpf(1.0f + t); u = EP[r] * e_pm; } while (0)
+#endif
 #if HX_ABL & 2
 #define HX_PROJ_PIECE_C(r, t, u) do { if (u * t == 123.456f) hx_store_u(e_rd, hx_pack_prod(u, t), e_voff, e_so + (((r) & 3) + 8 * ((r) >> 2)) * sstride); } while (0)
 #else
 #define HX_PROJ_PIECE_C(r, t, u) hx_store_u(e_rd, hx_pack_prod(u, t), e_voff, e_so + (((r) & 3) + 8 * ((r) >> 2)) * sstride)
 #endif
-#if HX_ABL & 32
+#if HX_ABL & (32 | 256)
 #define HX_PROJ_REINIT(EP, EG, r) do { } while (0)
 #else
 #define HX_PROJ_REINIT(EP, EG, r) do { EP[r] = sbn[acc_row(r, lane)]; EG[r] = sbn[256 + acc_row(r, lane)]; } while (0)
@@ -718,44 +763,61 @@ void launch_pair_transition_hx(genie_ctx* h, hipStream_t st, const PairLayerW& w
                        x.img, x.b1s, x.b2s, h->N, M, n_hb, x.sx, x.c1, x.c2);
 }
 
+// GENIE_HX_SLICE=n runs the three kernels of a triangle multiplication per slice of n structures, reusing
+// the same a / b / x buffers, so that (n = 2, N = 256: a + b + x = 201 MB) the operands stay in the
+// 256-MiB Infinity Cache between producer and consumer.  Measured: no gain (82.1 / 80.4 / 83.0 / 80.9
+// batch-steps/s for n = 8 / 4 / 2 / 1) -- these kernels are limited by the per-CU vector-memory pipe,
+// not by HBM bandwidth -- so the default is the whole batch; kept as a switch for larger N.
+static int g_hx_slice = 0;
+static int hx_slice() {
+    if (!g_hx_slice) { const char* e = getenv("GENIE_HX_SLICE"); g_hx_slice = e && atoi(e) > 0 ? atoi(e) : 1 << 20; }
+    return g_hx_slice;
+}
+
 void launch_trimul_hx(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgoing) {
     const int N = h->N, NP = h->NP, ntile = (N + 31) / 32;
-    const int n_wt = h->B * N * ntile;
     const int nw = hx_nw();
     const HxTriW& x = w.hx;
-    const unsigned cm_bytes = (unsigned)((size_t)h->B * 128 * NP * NP * 4);
     unsigned* acm = reinterpret_cast<unsigned*>(h->acm);
     unsigned* bcm = reinterpret_cast<unsigned*>(h->bcm);
-    const unsigned z_bytes = (unsigned)((size_t)h->B * N * N * 512);
-    {
-        ProfScope ps(h, st, KC_TRIMUL_PROJ);
-        const dim3 grid(hx_grid((n_wt + nw - 1) / nw, nw)), block(nw * 64);
-#define HX_PROJ(OUT, NWV) hipLaunchKernelGGL((k_trimul_proj_hx<OUT, NWV>), grid, block, HX_LDS_BYTES, st, h->p, h->rmaskf, x.img_proj, \
+    const int SB = hx_slice();
+    for (int b0 = 0; b0 < h->B; b0 += SB) {
+        const int nb = h->B - b0 < SB ? h->B - b0 : SB;
+        const int n_wt = nb * N * ntile;
+        const unsigned cm_bytes = (unsigned)((size_t)nb * 128 * NP * NP * 4);
+        const unsigned z_bytes = (unsigned)((size_t)nb * N * N * 512);
+        float* zs = h->p + (size_t)b0 * N * N * 128;
+        const float* ms = h->rmaskf + (size_t)b0 * N;
+        {
+            ProfScope ps(h, st, KC_TRIMUL_PROJ);
+            const dim3 grid(hx_grid((n_wt + nw - 1) / nw, nw)), block(nw * 64);
+#define HX_PROJ(OUT, NWV) hipLaunchKernelGGL((k_trimul_proj_hx<OUT, NWV>), grid, block, HX_LDS_BYTES, st, zs, ms, x.img_proj, \
                                              x.bias_proj, acm, bcm, N, NP, n_wt, cm_bytes, z_bytes, x.sx, x.cpa, x.cpb, x.cg)
-        if (outgoing) HX_PROJ(true, 8);
-        else HX_PROJ(false, 8);
+            if (outgoing) HX_PROJ(true, 8);
+            else HX_PROJ(false, 8);
 #undef HX_PROJ
-    }
-    {
-        ProfScope ps(h, st, KC_TRIMUL_CONTRACT);
-        const int BC = h->B * h->d.c_hidden_mul;
-        const int ncu = hx_num_cu();
-        if (NP >= 128) {
-            const int tiles = (NP + 127) / 128;
-            const int n_tiles = tiles * tiles * ((BC + 7) / 8) * 8;
-            hipLaunchKernelGGL(k_trimul_contract_hx<2>, dim3(n_tiles < 3 * ncu ? n_tiles : 3 * ncu), dim3(256), 2 * 4 * 128 * CX_ROWB, st,
-                               acm, bcm, h->xcm, NP, BC, cm_bytes, x.cx);
-        } else {
-            const int tiles = (NP + 63) / 64;
-            const int n_tiles = tiles * tiles * ((BC + 7) / 8) * 8;
-            hipLaunchKernelGGL(k_trimul_contract_hx<1>, dim3(n_tiles < 4 * ncu ? n_tiles : 4 * ncu), dim3(256), 2 * 4 * 64 * CX_ROWB, st,
-                               acm, bcm, h->xcm, NP, BC, cm_bytes, x.cx);
         }
-    }
-    {
-        ProfScope ps(h, st, KC_TRIMUL_OUT);
-        hipLaunchKernelGGL(k_trimul_out_hx<8>, dim3(hx_grid((n_wt + 7) / 8, 8)), dim3(512), HX_LDS_BYTES, st, h->p, h->xcm, x.img_out,
-                           x.bgs, x.bzs, N, NP, n_wt, cm_bytes, z_bytes, x.sx, x.cgo, x.cz);
+        {
+            ProfScope ps(h, st, KC_TRIMUL_CONTRACT);
+            const int BC = nb * h->d.c_hidden_mul;
+            const int ncu = hx_num_cu();
+            if (NP >= 128) {
+                const int tiles = (NP + 127) / 128;
+                const int n_tiles = tiles * tiles * ((BC + 7) / 8) * 8;
+                hipLaunchKernelGGL(k_trimul_contract_hx<2>, dim3(n_tiles < 3 * ncu ? n_tiles : 3 * ncu), dim3(256), 2 * 4 * 128 * CX_ROWB, st,
+                                   acm, bcm, h->xcm, NP, BC, cm_bytes, x.cx);
+            } else {
+                const int tiles = (NP + 63) / 64;
+                const int n_tiles = tiles * tiles * ((BC + 7) / 8) * 8;
+                hipLaunchKernelGGL(k_trimul_contract_hx<1>, dim3(n_tiles < 4 * ncu ? n_tiles : 4 * ncu), dim3(256), 2 * 4 * 64 * CX_ROWB, st,
+                                   acm, bcm, h->xcm, NP, BC, cm_bytes, x.cx);
+            }
+        }
+        {
+            ProfScope ps(h, st, KC_TRIMUL_OUT);
+            hipLaunchKernelGGL(k_trimul_out_hx<8>, dim3(hx_grid((n_wt + 7) / 8, 8)), dim3(512), HX_LDS_BYTES, st, zs, h->xcm, x.img_out,
+                               x.bgs, x.bzs, N, NP, n_wt, cm_bytes, z_bytes, x.sx, x.cgo, x.cz);
+        }
     }
 }
 

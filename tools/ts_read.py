@@ -28,25 +28,33 @@ for _ in range(3):
     eng.denoise(x, r, ts, None)
 torch.cuda.synchronize()
 lib = C.CDLL(capi.LIB_PATH)
-buf = np.zeros((8, 4096), dtype=np.uint64)
+buf = np.zeros((24, 4096), dtype=np.uint64)
 rc = lib.genie_hx_debug_read(buf.ctypes.data_as(C.c_void_p))
 assert rc == 0, rc
-PER_TILE = 1 + 8 * 4
-names = ['mfma+epilogue', 'vmcnt wait', 'barrier', 'to next stage start']
-for w in (0, 2, 4, 6):
-    t = buf[w].astype(np.int64)
-    n = int((t > 0).sum())
-    tiles = n // PER_TILE
-    if tiles == 0:
+t = buf.astype(np.int64)
+# projection (variant 0 = incoming, 1 = outgoing): per tile 1 + 8 x (start, after mfma, after vmcnt, after barrier)
+for var in (0, 1):
+    rows = []
+    for w in range(8):
+        x = t[var * 8 + w]
+        n = int((x > 0).sum()) // 33
+        if n == 0:
+            continue
+        x = x[:n * 33].reshape(n, 33)
+        st = x[:, 1:].reshape(n, 8, 4)
+        d = np.diff(st, axis=2).mean(axis=(0, 1))
+        rows.append((w, (x[:, 1] - x[:, 0]).mean(), *d, np.diff(x[:, 0]).mean() if n > 1 else 0))
+    print(f'projection variant {var}: wave  prologue  mfma+epi  vmcnt  barrier  tile period')
+    for r in rows:
+        print('   ', ' '.join(f'{v:9.0f}' for v in r))
+# pair transition (variant 2): per stage (start, after GEMM1, after split + GEMM2, after barrier)
+print('transition: wave  gemm1  split+gemm2  barrier  stage period  max stage->stage gap (tile boundary)')
+for w in range(8):
+    x = t[16 + w]
+    n = int((x > 0).sum()) // 4 * 4
+    if n < 8:
         continue
-    t = t[:tiles * PER_TILE].reshape(tiles, PER_TILE)
-    pro = (t[:, 1] - t[:, 0]).mean()
-    st = t[:, 1:].reshape(tiles, 8, 4)
-    d = np.diff(st, axis=2).mean(axis=(0, 1))            # within-stage phases
-    nxt = (st[:, 1:, 0] - st[:, :-1, 3]).mean()          # stage end -> next stage start
-    tile_total = (t[1:, 0] - t[:-1, 0]).mean() if tiles > 1 else float('nan')
-    print(f'variant {w // 4} wg {64 * (w % 4)}: tiles {tiles}  prologue {pro:.0f}  ' + '  '.join(f'{nm} {v:.0f}' for nm, v in zip(names, list(d) + [nxt]))
-          + f'  | tile period {tile_total:.0f} (100 MHz ticks x?)')
-    print('   per-stage mfma phase by pass:', np.diff(st, axis=2)[:, :, 0].mean(axis=0).round(0))
-    print('   per-stage wait by pass      :', np.diff(st, axis=2)[:, :, 1].mean(axis=0).round(0))
-    print('   per-stage barrier by pass   :', np.diff(st, axis=2)[:, :, 2].mean(axis=0).round(0))
+    st = x[:n].reshape(-1, 4)
+    d = np.diff(st, axis=1)
+    gap = st[1:, 0] - st[:-1, 3]
+    print('   ', w, f'{d[:, 0].mean():9.0f} {d[:, 1].mean():9.0f} {d[:, 2].mean():9.0f} {np.median(np.diff(st[:, 0])):9.0f} {gap.max():9.0f}')
