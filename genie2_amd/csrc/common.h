@@ -10,11 +10,12 @@
 // and MFMA e pairs k = 8kb+e (lanes < 32) with k = 8kb+4+e (lanes >= 32).
 // Weights are repacked once on the host into that order ("fragment-major"):
 //   Wp[((nb*KB + kb)*64 + lane)*4 + e] = W[32nb + (lane&31)][8kb + 4(lane>>5) + e]
-// so a wave fetches a whole fragment with ONE coalesced 1-KiB global_load_dwordx4
-// (L2 resident: the largest weight is 3.2 MB) and needs no LDS staging or
-// barrier for weights.  Activations are staged per tile in LDS, K-contiguous
-// with a +4 float row pad, which makes the float4 fragment read
-// (ds_read_b128, 16-lane groups, bank = (addr/4) % 64) conflict free.
+// so a whole fragment is ONE coalesced 1-KiB transfer: k_gemm_rows streams them into a register
+// ring, the pair-stack kernels pull 32-KiB stages into LDS with LDS-DMA (pair_wl_kernels.hip).
+// LDS tiles of activations are K-contiguous with a +4 float row pad, which makes the float4
+// fragment read (ds_read_b128, 16-lane groups, bank = (addr/4) % 64) conflict free.
+// The default pair-stack arithmetic is NOT this instruction but three f16 MFMAs on split
+// operands: hx.h.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
