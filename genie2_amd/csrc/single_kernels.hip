@@ -675,6 +675,208 @@ __global__ void k_scale_copy(const float* __restrict__ in, float* __restrict__ o
 }
 
 // ---------------------------------------------------------------------------
+// IPA attention core, Q queries per work-group (same maths as k_ipa_attn_t, which stays as the
+// single-query form).  A work-group of 512 threads handles queries i0..i0+Q-1 of one structure:
+// every K / K-point / V / V-point value fetched from L2 is used for Q queries, which divides the
+// kernel's dominant traffic (0.85 MB of L2 reads per query in the single-query form: 10.7 TB/s of
+// L2 bandwidth at 163 us) by Q.  Logits: thread = (j, half of the heads); o / o_pt: thread = output
+// column, Q accumulators; o_pair: the Q p-rows are streamed one after the other.
+// ---------------------------------------------------------------------------
+template <int H, int C, int PQ, int PV, int Q>
+__global__ __launch_bounds__(512) void k_ipa_attn_q(const float* __restrict__ proj, int ldp, const float* __restrict__ kT,
+                                                    const float* __restrict__ v, const float* __restrict__ qp,
+                                                    const float* __restrict__ kpT, const float* __restrict__ vp,
+                                                    const float* __restrict__ bias, const float* __restrict__ z,
+                                                    const float* __restrict__ rots, const float* __restrict__ trans,
+                                                    const float* __restrict__ rmask, const float* __restrict__ head_w,
+                                                    float* __restrict__ cat, int B, int N, int layer) {
+    constexpr int CP = 128, HC = H * C, NQP = H * PQ * 3, NPT = H * PV * 3, NCAT = HC + H * PV * 4 + H * CP, HH = H / 2;
+    static_assert(H % 2 == 0 && C % 4 == 0 && HC + NPT <= 512, "shape");
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int NP8 = (N + 7) & ~7;
+    float* att = sm;                            // [Q][H][NP8], zero padded
+    float* sq = att + Q * H * NP8;              // [Q][HC]
+    float* sqp = sq + Q * HC;                   // [Q][NQP]
+    float* shw = sqp + Q * NQP;                 // [H] (16 reserved)
+    float* opt = shw + 16;                      // [Q][NPT]
+    float* red = opt + Q * NPT;                 // [4][H][CP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int groups = (N + Q - 1) / Q;
+    const int b = blockIdx.x / groups, i0 = (blockIdx.x % groups) * Q;
+    const int nq = min(Q, N - i0);
+    for (int u = tid; u < Q * HC; u += 512) { const int q = u / HC; sq[u] = proj[(size_t)(b * N + min(i0 + q, N - 1)) * ldp + (u - q * HC)]; }
+    for (int u = tid; u < Q * NQP; u += 512) { const int q = u / NQP; sqp[u] = qp[(size_t)(b * N + min(i0 + q, N - 1)) * NQP + (u - q * NQP)]; }
+    if (tid < H) {
+        const float g = head_w[tid];
+        const float sp = (g > 20.f) ? g : log1pf(expf(g));
+        shw[tid] = sp * sqrtf(1.0f / (3.0f * ((float)PQ * 9.0f / 2.0f)));
+    }
+    __syncthreads();
+    const float s_qk = sqrtf(1.0f / (3.0f * (float)C)), s_b = sqrtf(1.0f / 3.0f);
+    {
+        const int hg = tid >> 8;                 // heads hg*HH .. hg*HH + HH - 1
+        for (int j = tid & 255; j < NP8; j += 256) {
+            const int jc = min(j, N - 1);
+            const float mj = rmask[b * N + jc];
+            float sqm[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) sqm[q] = 1e5f * (rmask[b * N + min(i0 + q, N - 1)] * mj - 1.0f);
+#pragma unroll 1
+            for (int h2 = 0; h2 < HH; ++h2) {
+                const int hh = hg * HH + h2;
+                const float* kc = kT + (((size_t)b * H + hh) * C) * N + jc;
+                float kv[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) kv[c] = kc[(size_t)c * N];
+                const float* kp = kpT + ((((size_t)b * H + hh) * PQ) * 3) * N + jc;
+                float kpv[PQ * 3];
+#pragma unroll
+                for (int c = 0; c < PQ * 3; ++c) kpv[c] = kp[(size_t)c * N];
+                float bia[Q];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) bia[q] = bias[((((size_t)layer * H + hh) * B + b) * N + min(i0 + q, N - 1)) * N + jc];
+                const float hw = shw[hh];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const float* qv = sq + q * HC + hh * C;
+                    float qk = 0.f;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) qk += qv[c] * kv[c];
+                    float a = qk * s_qk;
+                    a += s_b * bia[q];
+                    const float* qpv = sqp + q * NQP + hh * PQ * 3;
+                    float pt = 0.f;
+#pragma unroll
+                    for (int pp = 0; pp < PQ; ++pp) {
+                        const float dx = qpv[pp * 3 + 0] - kpv[pp * 3 + 0];
+                        const float dy = qpv[pp * 3 + 1] - kpv[pp * 3 + 1];
+                        const float dz = qpv[pp * 3 + 2] - kpv[pp * 3 + 2];
+                        pt += ((dx * dx + dy * dy) + dz * dz) * hw;
+                    }
+                    a += pt * (-0.5f);
+                    a += sqm[q];
+                    att[(q * H + hh) * NP8 + j] = (j < N) ? a : -3.0e38f;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int rr = wave; rr < Q * H; rr += 8) {
+        float* ar = att + rr * NP8;
+        float mx = -3.0e38f;
+        for (int j = lane; j < N; j += 64) mx = fmaxf(mx, ar[j]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float s = 0.f;
+        for (int j = lane; j < N; j += 64) { const float e = expf(ar[j] - mx); ar[j] = e; s += e; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        for (int j = lane; j < NP8; j += 64) ar[j] = (j < N) ? ar[j] / s : 0.f;
+    }
+    __syncthreads();
+    // o and o_pt: one output column per thread, Q accumulators, j unrolled x8
+    if (tid < HC + NPT) {
+        const bool isv = tid < HC;
+        const int w = isv ? tid : tid - HC;
+        const int hh = isv ? (tid / C) : (w / (PV * 3));
+        const float* vv = isv ? v + (size_t)b * N * HC + tid : vp + (size_t)b * N * NPT + w;
+        const int ld = isv ? HC : NPT;
+        float acc[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) acc[q] = 0.f;
+        for (int j0 = 0; j0 < NP8; j0 += 8) {
+            float x[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = vv[(size_t)min(j0 + k, N - 1) * ld];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const float* ar = att + (q * H + hh) * NP8 + j0;
+                const float4 a0 = *reinterpret_cast<const float4*>(ar), a1 = *reinterpret_cast<const float4*>(ar + 4);
+                acc[q] += a0.x * x[0]; acc[q] += a0.y * x[1]; acc[q] += a0.z * x[2]; acc[q] += a0.w * x[3];
+                acc[q] += a1.x * x[4]; acc[q] += a1.y * x[5]; acc[q] += a1.z * x[6]; acc[q] += a1.w * x[7];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            if (q < nq) {
+                if (isv) cat[(size_t)(b * N + i0 + q) * NCAT + tid] = acc[q];
+                else opt[q * NPT + w] = acc[q];
+            }
+        }
+    }
+    // o_pair, one query after the other: thread = (channel quad c4, j-group jg of 16); 8 rows in flight
+    const int c4 = tid & 31, jg = tid >> 5;
+#pragma unroll 1
+    for (int q = 0; q < nq; ++q) {
+        const int row = b * N + i0 + q;
+        float4 acc[H];
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) acc[hh] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* zr = z + ((size_t)row * N) * CP + c4 * 4;
+        const float* aq = att + q * H * NP8;
+        for (int jb = jg * 8; jb < NP8; jb += 128) {        // 8 consecutive rows per thread: attention weights as two b128 reads
+            float4 zz[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) zz[k] = *reinterpret_cast<const float4*>(zr + (size_t)min(jb + k, N - 1) * CP);
+#pragma unroll
+            for (int hh = 0; hh < H; ++hh) {
+                const float4 a0 = *reinterpret_cast<const float4*>(aq + hh * NP8 + jb), a1 = *reinterpret_cast<const float4*>(aq + hh * NP8 + jb + 4);
+                const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};     // zero for j >= N (padding)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    acc[hh].x += a[k] * zz[k].x; acc[hh].y += a[k] * zz[k].y; acc[hh].z += a[k] * zz[k].z; acc[hh].w += a[k] * zz[k].w;
+                }
+            }
+        }
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) {         // the two half-waves of a wave hold different j-groups
+            acc[hh].x += __shfl_xor(acc[hh].x, 32); acc[hh].y += __shfl_xor(acc[hh].y, 32);
+            acc[hh].z += __shfl_xor(acc[hh].z, 32); acc[hh].w += __shfl_xor(acc[hh].w, 32);
+        }
+        if (wave < 4 && lane < 32) {
+#pragma unroll
+            for (int hh = 0; hh < H; ++hh) *reinterpret_cast<float4*>(red + ((size_t)wave * H + hh) * CP + c4 * 4) = acc[hh];
+        }
+        __syncthreads();
+        if (wave >= 4 && lane < 32) {
+#pragma unroll
+            for (int hh = 0; hh < H; ++hh) {
+                float4* pr = reinterpret_cast<float4*>(red + ((size_t)(wave - 4) * H + hh) * CP + c4 * 4);
+                float4 t = *pr;
+                t.x += acc[hh].x; t.y += acc[hh].y; t.z += acc[hh].z; t.w += acc[hh].w;
+                *pr = t;
+            }
+        }
+        __syncthreads();
+        {
+            float* op = cat + (size_t)row * NCAT + HC + H * PV * 4;
+            constexpr int tot = H * CP;
+            for (int u = tid; u < tot; u += 512) op[u] = (red[u] + red[tot + u]) + (red[2 * tot + u] + red[3 * tot + u]);
+        }
+        __syncthreads();
+    }
+    {
+        constexpr int np = H * PV;
+        for (int u = tid; u < nq * np; u += 512) {
+            const int q = u / np, w = u - q * np;
+            const int row = b * N + i0 + q;
+            const float* R = rots + (size_t)row * 9;
+            const float* t = trans + (size_t)row * 3;
+            const float* o3 = opt + q * NPT + w * 3;
+            const float x = o3[0] - t[0], y = o3[1] - t[1], zc = o3[2] - t[2];
+            const float lx = R[0] * x + R[3] * y + R[6] * zc;
+            const float ly = R[1] * x + R[4] * y + R[7] * zc;
+            const float lz = R[2] * x + R[5] * y + R[8] * zc;
+            float* crow = cat + (size_t)row * NCAT;
+            crow[HC + w] = lx;
+            crow[HC + np + w] = ly;
+            crow[HC + 2 * np + w] = lz;
+            crow[HC + 3 * np + w] = sqrtf(((lx * lx + ly * ly) + lz * lz) + 1e-8f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 void launch_single_input(genie_ctx* h, hipStream_t st, const int32_t* timesteps) {
@@ -710,8 +912,17 @@ void launch_ipa_prep(genie_ctx* h, hipStream_t st) {
 static bool ipa_is_base(const genie_dims_t& d) {
     return d.n_head_ipa == 12 && d.c_hidden_ipa == 16 && d.n_qk_point == 4 && d.n_v_point == 8 && d.c_p == 128;
 }
-static size_t ipa_attn_t_lds(const genie_dims_t& d, int N) {
+#define IPA_Q 4
+static size_t ipa_attn_t1_lds(const genie_dims_t& d, int N) {      // k_ipa_attn_t<12, 16, 4, 8> (single query; long structures)
     return ((size_t)d.n_head_ipa * ((N + 7) & ~7) + 4 * d.n_head_ipa * d.c_p + d.n_head_ipa * d.n_v_point * 3) * sizeof(float);
+}
+static size_t ipa_attn_q_lds(const genie_dims_t& d, int N);
+static bool ipa_use_q(const genie_dims_t& d, int N) { return ipa_attn_q_lds(d, N) <= 160 * 1024; }
+static size_t ipa_attn_t_lds(const genie_dims_t& d, int N) { return ipa_use_q(d, N) ? ipa_attn_q_lds(d, N) : ipa_attn_t1_lds(d, N); }
+static size_t ipa_attn_q_lds(const genie_dims_t& d, int N) {       // k_ipa_attn_q<12, 16, 4, 8, IPA_Q>
+    const size_t H = d.n_head_ipa;
+    return ((size_t)IPA_Q * H * ((N + 7) & ~7) + IPA_Q * H * d.c_hidden_ipa + IPA_Q * H * d.n_qk_point * 3 + 16 +
+            IPA_Q * H * d.n_v_point * 3 + 4 * H * d.c_p) * sizeof(float);
 }
 size_t ipa_attn_lds(const genie_dims_t& d, int N) {
     if (ipa_is_base(d)) return ipa_attn_t_lds(d, N);
@@ -722,10 +933,16 @@ void launch_ipa_attn(genie_ctx* h, hipStream_t st, int layer, const float* head_
     ProfScope ps(h, st, KC_IPA_ATTN);
     const genie_dims_t& d = h->d;
     const int ldp = d.n_head_ipa * (3 * d.c_hidden_ipa + 3 * d.n_qk_point + 3 * (d.n_qk_point + d.n_v_point));
-    if (ipa_is_base(d)) {
-        hipLaunchKernelGGL((k_ipa_attn_t<12, 16, 4, 8>), dim3(h->B * h->N), dim3(256), ipa_attn_t_lds(d, h->N), st, h->proj, ldp,
+    if (ipa_is_base(d) && !ipa_use_q(d, h->N)) {
+        hipLaunchKernelGGL((k_ipa_attn_t<12, 16, 4, 8>), dim3(h->B * h->N), dim3(256), ipa_attn_t1_lds(d, h->N), st, h->proj, ldp,
                            h->kT, h->v, h->qp, h->kpT, h->vp, h->ipa_bias, h->p, h->rots_w, h->trans_w, h->rmaskf, head_w, h->cat,
                            h->B, h->N, layer);
+        return;
+    }
+    if (ipa_is_base(d)) {
+        hipLaunchKernelGGL((k_ipa_attn_q<12, 16, 4, 8, IPA_Q>), dim3(h->B * ((h->N + IPA_Q - 1) / IPA_Q)), dim3(512),
+                           ipa_attn_t_lds(d, h->N), st, h->proj, ldp, h->kT, h->v, h->qp, h->kpT, h->vp, h->ipa_bias, h->p, h->rots_w,
+                           h->trans_w, h->rmaskf, head_w, h->cat, h->B, h->N, layer);
         return;
     }
     hipLaunchKernelGGL(k_ipa_attn, dim3(h->B * h->N), dim3(256), ipa_attn_lds(d, h->N), st, h->proj, ldp, h->kT, h->v, h->qp,
@@ -767,10 +984,14 @@ void launch_scale_copy(genie_ctx* h, hipStream_t st, const float* in, float* out
 }
 
 void single_kernels_init(const genie_dims_t& d, int n_max) {
-    if (ipa_is_base(d))
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn_t<12, 16, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)ipa_attn_t_lds(d, n_max));
-    else
+    if (ipa_is_base(d)) {
+        if (ipa_use_q(d, n_max))
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn_q<12, 16, 4, 8, IPA_Q>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)ipa_attn_q_lds(d, n_max));
+        else
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn_t<12, 16, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)ipa_attn_t1_lds(d, n_max));
+    } else
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)ipa_attn_lds(d, n_max));
 }
