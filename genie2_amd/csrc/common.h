@@ -185,6 +185,8 @@ struct StructLayerW {
     float *bb_w, *bb_b;           // raw [6][384], [6]
 };
 
+struct HxGemmW { const float* w; const unsigned char* img; float inv_s; };   // hx image of a k_gemm_rows weight (keyed by its f32 pack)
+
 struct genie_ctx {
     genie_dims_t d;
     int device;
@@ -195,6 +197,7 @@ struct genie_ctx {
     float* wdev;                  // one device allocation holding everything below
     bool hx;                      // pair-stack GEMMs in split-f16 arithmetic (hx.h); GENIE_MATH=f32 selects the f32-MFMA kernels
     unsigned char* hxdev;         // device allocation of the hx weight images
+    HxGemmW hxg[64]; int n_hxg;   // hx images of the row-GEMM weights
     size_t wdev_floats;
     float *single_w;              // packed [384][856]
     float *pij_w;                 // packed [256][384]: linear_s_p_i | linear_s_p_j

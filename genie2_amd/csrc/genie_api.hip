@@ -243,6 +243,20 @@ int genie_load_weights(genie_handle_t h, const float* blob, size_t n_floats) {
     std::vector<std::pair<float**, size_t>> fix;     // (pointer slot, offset)
     std::vector<std::pair<const unsigned char**, size_t>> hxfix;
     auto slot = [&](float** s, size_t off) { fix.push_back({s, off}); };
+    // row-GEMM weight: the f32 fragment pack plus its hx image (units (nb, k16): 32 output columns x 16 k)
+    struct GemmFix { float** slot; size_t hx_off; float inv_s; };
+    std::vector<GemmFix> gfix;
+    auto pack_gemm = [&](float** s, const float* W, int rows, int cols) {
+        slot(s, img.pack(W, rows, cols));
+        const float sw = p2floor(16384.0 / max_abs(W, (size_t)rows * cols));
+        gfix.push_back({s, hx.begin(), 1.0f / sw});
+        const int NB = (rows + 31) / 32, KC = (cols + 15) / 16;
+        for (int nb = 0; nb < NB; ++nb)
+            for (int kc = 0; kc < KC; ++kc)
+                hx.unit([&](int j, int hh, int e) {
+                    const int r = 32 * nb + j, k = 16 * kc + 8 * hh + e;
+                    return (r < rows && k < cols) ? W[(size_t)r * cols + k] * sw : 0.f; });
+    };
 
     size_t ones_off, zeros_off;
     {
@@ -251,12 +265,12 @@ int genie_load_weights(genie_handle_t h, const float* blob, size_t n_floats) {
         zeros_off = img.raw(zero.data(), zero.size());
     }
     const int nsi = single_in(d);
-    slot(&h->single_w, img.pack(c.take(cs * nsi), (int)cs, nsi));
+    pack_gemm(&h->single_w, c.take(cs * nsi), (int)cs, nsi);
     {
         const float* wi = c.take(cp * cs);
         const float* wj = c.take(cp * cs);
         auto v = vcat({{wi, cp * cs}, {wj, cp * cs}});
-        slot(&h->pij_w, img.pack(v.data(), (int)(2 * cp), (int)cs));
+        pack_gemm(&h->pij_w, v.data(), (int)(2 * cp), (int)cs);
     }
     {
         const int nr = 2 * d.relpos_k + 3;
@@ -393,15 +407,15 @@ int genie_load_weights(genie_handle_t h, const float* blob, size_t n_floats) {
         slot(&S.head_w, img.raw(hw, H));
         auto w = vcat({{q_w, H * C * cs}, {kv_w, 2 * H * C * cs}, {qp_w, 3 * H * Pq * cs}, {kp_w, 3 * H * (Pq + Pv) * cs}});
         auto bv = vcat({{q_b, H * C}, {kv_b, 2 * H * C}, {qp_b, 3 * H * Pq}, {kp_b, 3 * H * (Pq + Pv)}});
-        slot(&S.proj_w, img.pack(w.data(), ipa_proj_n(d), (int)cs));
+        pack_gemm(&S.proj_w, w.data(), ipa_proj_n(d), (int)cs);
         slot(&S.proj_b, img.raw(bv.data(), bv.size()));
         wb_all.insert(wb_all.end(), b_w, b_w + H * cp);
         bb_all.insert(bb_all.end(), b_b, b_b + H);
-        slot(&S.out_w, img.pack(o_w, (int)cs, (int)ncat)); slot(&S.out_b, img.raw(o_b, cs));
+        pack_gemm(&S.out_w, o_w, (int)cs, (int)ncat); slot(&S.out_b, img.raw(o_b, cs));
         slot(&S.ln_ipa_g, img.raw(li_g, cs)); slot(&S.ln_ipa_b, img.raw(li_b, cs));
-        slot(&S.t1_w, img.pack(t1w, (int)cs, (int)cs)); slot(&S.t1_b, img.raw(t1b, cs));
-        slot(&S.t2_w, img.pack(t2w, (int)cs, (int)cs)); slot(&S.t2_b, img.raw(t2b, cs));
-        slot(&S.t3_w, img.pack(t3w, (int)cs, (int)cs)); slot(&S.t3_b, img.raw(t3b, cs));
+        pack_gemm(&S.t1_w, t1w, (int)cs, (int)cs); slot(&S.t1_b, img.raw(t1b, cs));
+        pack_gemm(&S.t2_w, t2w, (int)cs, (int)cs); slot(&S.t2_b, img.raw(t2b, cs));
+        pack_gemm(&S.t3_w, t3w, (int)cs, (int)cs); slot(&S.t3_b, img.raw(t3b, cs));
         slot(&S.ln_tr_g, img.raw(lt_g, cs)); slot(&S.ln_tr_b, img.raw(lt_b, cs));
         slot(&S.bb_w, img.raw(bw, 6 * cs)); slot(&S.bb_b, img.raw(bbs, 6));
     }
@@ -420,6 +434,9 @@ int genie_load_weights(genie_handle_t h, const float* blob, size_t n_floats) {
     HIP_TRY(h, hipMalloc((void**)&h->hxdev, hx.d.size() * 2 + 256));
     HIP_TRY(h, hipMemcpy(h->hxdev, hx.d.data(), hx.d.size() * 2, hipMemcpyHostToDevice));
     for (auto& f : hxfix) *f.first = h->hxdev + f.second;
+    h->n_hxg = 0;
+    for (auto& g : gfix)
+        if (h->n_hxg < 64) h->hxg[h->n_hxg++] = HxGemmW{*g.slot, h->hxdev + g.hx_off, g.inv_s};
     h->have_weights = true;
     return GENIE_OK;
 }

@@ -1,6 +1,7 @@
 // Single-track kernels: single feature net, row GEMMs, LayerNorm, invariant
 // point attention, backbone update.  Reference lines are cited per kernel.
-#include "common.h"
+#include <type_traits>
+#include "hx.h"
 
 // ---------------------------------------------------------------------------
 // Single feature net input (single_feature_net.py:103-142): one row per
@@ -116,6 +117,133 @@ __global__ __launch_bounds__(256) void k_gemm_rows(const float* __restrict__ A, 
         const int row = r0 + acc_row(r, lane);
         if (row < M) {
             float v = acc[r] + bc;
+            if (relu) v = fmaxf(v, 0.f);
+            if (res) v += res[(size_t)row * ldr + col];
+            if (rowmask) v *= rowmask[row];
+            out[(size_t)row * ldo + col] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The same Linear in hx arithmetic (hx.h): three f16 MFMAs per product on split operands.
+// The activations of the single track have no load-time bound (IPA outputs carry pair values and
+// coordinates), so they are split BLOCK-FLOATING-POINT: each (row, 64-wide K chunk) gets its own
+// power-of-two scale from its largest magnitude (16 lanes share a row chunk: 4 shuffles), the chunk
+// is accumulated in a fresh accumulator and folded into the running sum with the inverse scale
+// (16 FMAs per 12 MFMAs).  Weight units (hi + lo fragment of 32 columns x 16 k) stream from L2
+// through an asm-issued register ring of 8 units; every wait count is static (in-order retirement):
+//   releasing a ring unit : younger = 7 other units (14 loads) + 2 x 2 A loads          = 18
+//   releasing the A loads : younger = the 4 refills of this chunk (8 loads)             = 8
+// (Measured: deeper rings / activation prefetch / split accumulator chains do not help -- at M = B N rows these launches
+//  are bounded by fixed latencies, tools/trace_gemm.sh: 13 us for 192 work-groups of 72 MFMAs per wave.)
+// ---------------------------------------------------------------------------
+#define GH_ROWB 144          // bytes per row of a 64-k plane of halves (128 + 16 pad: conflict-free b128 reads)
+#define GH_PD 8
+__global__ __launch_bounds__(256) void k_gemm_rows_hx(const float* __restrict__ A, int lda, int M, int K,
+                                                      const unsigned char* __restrict__ Wx, int Nout, float inv_sw,
+                                                      const float* __restrict__ bias, const float* __restrict__ res, int ldr,
+                                                      const float* __restrict__ rowmask, int relu, float* __restrict__ out, int ldo) {
+    __shared__ __attribute__((aligned(16))) unsigned char sa[2][2][32 * GH_ROWB];   // [buffer][hi | lo]
+    __shared__ __attribute__((aligned(16))) float sinv[2][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * 32;
+    const int nb = min((int)(blockIdx.y * 4 + wave), (Nout + 31) / 32 - 1);   // idle waves shadow the last block
+    const bool active = (int)(blockIdx.y * 4 + wave) * 32 < Nout;
+    const int KC = (K + 15) >> 4;                // 16-wide weight units
+    const int nkc = (K + 63) >> 6;               // 64-wide activation chunks
+    const int lr = tid >> 4, c4 = tid & 15;      // 16 rows x 16 float4 per pass, 2 passes
+    const float* wbase = reinterpret_cast<const float*>(Wx + (size_t)nb * KC * 2048) + lane * 4;   // unit u: + u*512 floats; lo: + 256
+
+    v4f wh[GH_PD], wl[GH_PD];
+#pragma unroll
+    for (int s = 0; s < GH_PD; ++s) {
+        const float* p = wbase + (size_t)min(s, KC - 1) * 512;
+        wf_issue(wh[s], p);
+        wf_issue(wl[s], p + 256);
+    }
+    v4f ra0, ra1;
+    auto a_addr = [&](int kc, int u) {
+        const int r = min(r0 + lr + 16 * u, M - 1), k = min(kc * 64 + c4 * 4, K - 4);
+        return A + (size_t)r * lda + k;
+    };
+    auto split_store = [&](v4f v, int row, int buf) {
+        float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4)); m = fmaxf(m, __shfl_xor(m, 8));
+        const int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 255u);          // biased exponent of the chunk's largest |a|
+        const bool tiny = e < 16;                                                      // (all ~0: any scale will do)
+        const float sc = tiny ? 1.0f : __builtin_bit_cast(float, (unsigned)(268 - e) << 23);    // max * sc in [2^14, 2^15)
+        const float isc = tiny ? 1.0f : __builtin_bit_cast(float, (unsigned)(e - 14) << 23);
+        unsigned h01, l01, h23, l23;
+        hx_split2(v.x, v.y, sc, h01, l01);
+        hx_split2(v.z, v.w, sc, h23, l23);
+        *reinterpret_cast<uint2*>(&sa[buf][0][row * GH_ROWB + c4 * 8]) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(&sa[buf][1][row * GH_ROWB + c4 * 8]) = make_uint2(l01, l23);
+        if (c4 == 0) sinv[buf][row] = isc;
+    };
+    auto a_store = [&](int kc, int buf) {
+        const bool kok = kc * 64 + c4 * 4 < K;
+        const v4f z4 = {0.f, 0.f, 0.f, 0.f};
+        split_store((kok && r0 + lr < M) ? ra0 : z4, lr, buf);
+        split_store((kok && r0 + lr + 16 < M) ? ra1 : z4, lr + 16, buf);
+    };
+    wf_issue(ra0, a_addr(0, 0));
+    wf_issue(ra1, a_addr(0, 1));
+    wf_wait<0>(ra0, ra1);
+    a_store(0, 0);
+    __syncthreads();
+
+    f32x16 acc = zero16();
+    const int foff = (lane & 31) * GH_ROWB + (lane >> 5) * 16;
+    // chunk body with a COMPILE-TIME ring half (slots 4 PAR .. 4 PAR + 3): an asm load into a dynamically indexed register
+    // array would land in a temporary the compiler has already copied from
+    auto chunk = [&](int kc, auto par_tag) {
+        constexpr int PAR = decltype(par_tag)::value;
+        const int kcn = min(kc + 1, nkc - 1);            // last chunk: harmless re-load keeps the counts uniform
+        wf_issue(ra0, a_addr(kcn, 0));
+        wf_issue(ra1, a_addr(kcn, 1));
+        const unsigned char* cur = &sa[PAR][0][0] + foff;
+        f32x16 part = zero16();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const h8 ah = *reinterpret_cast<const h8*>(cur + q * 32);
+            const h8 al = *reinterpret_cast<const h8*>(cur + 32 * GH_ROWB + q * 32);
+            wf_wait<2 * GH_PD + 2>(wh[PAR * 4 + q], wl[PAR * 4 + q]);
+            const h8 bh = __builtin_bit_cast(h8, wh[PAR * 4 + q]), bl = __builtin_bit_cast(h8, wl[PAR * 4 + q]);
+            MFH3(ah, al, bh, bl, part);
+            __builtin_amdgcn_sched_barrier(0);
+            const float* p = wbase + (size_t)min(kc * 4 + q + GH_PD, KC - 1) * 512;
+            wf_issue(wh[PAR * 4 + q], p);
+            wf_issue(wl[PAR * 4 + q], p + 256);
+        }
+        {   // fold the chunk in with the inverse of its row scales (rows 8g + 4h .. + 3 are contiguous)
+            const float* si = sinv[PAR] + 4 * (lane >> 5);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 iv = *reinterpret_cast<const float4*>(si + 8 * g);
+                acc[4 * g] = fmaf(part[4 * g], iv.x, acc[4 * g]); acc[4 * g + 1] = fmaf(part[4 * g + 1], iv.y, acc[4 * g + 1]);
+                acc[4 * g + 2] = fmaf(part[4 * g + 2], iv.z, acc[4 * g + 2]); acc[4 * g + 3] = fmaf(part[4 * g + 3], iv.w, acc[4 * g + 3]);
+            }
+        }
+        wf_wait<GH_PD>(ra0, ra1);
+        a_store(kcn, PAR ^ 1);
+        __syncthreads();
+    };
+    for (int kc = 0; kc < nkc; kc += 2) {
+        chunk(kc, std::integral_constant<int, 0>{});
+        if (kc + 1 < nkc) chunk(kc + 1, std::integral_constant<int, 1>{});
+    }
+#pragma unroll
+    for (int s = 0; s < GH_PD; ++s) wf_wait<0>(wh[s], wl[s]);
+    if (!active) return;
+    const int col = nb * 32 + (lane & 31);
+    if (col >= Nout) return;
+    const float bc = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = r0 + acc_row(r, lane);
+        if (row < M) {
+            float v = fmaf(acc[r], inv_sw, bc);
             if (relu) v = fmaxf(v, 0.f);
             if (res) v += res[(size_t)row * ldr + col];
             if (rowmask) v *= rowmask[row];
@@ -892,6 +1020,14 @@ void launch_gemm_rows(genie_ctx* h, hipStream_t st, const float* A, int lda, int
                       const float* bias, const float* res, int ldr, const float* rowmask, int relu, float* out, int ldo) {
     ProfScope ps(h, st, KC_GEMM_ROWS);
     dim3 grid((M + 31) / 32, (Nout + 127) / 128);
+    if (h->hx) {
+        for (int i = 0; i < h->n_hxg; ++i)
+            if (h->hxg[i].w == Wp) {
+                hipLaunchKernelGGL(k_gemm_rows_hx, grid, dim3(256), 0, st, A, lda, M, K, h->hxg[i].img, Nout, h->hxg[i].inv_s, bias, res,
+                                   ldr, rowmask, relu, out, ldo);
+                return;
+            }
+    }
     hipLaunchKernelGGL(k_gemm_rows, grid, dim3(256), 0, st, A, lda, M, K, Wp, Nout, bias, res, ldr, rowmask, relu, out, ldo);
 }
 
