@@ -53,16 +53,9 @@ __device__ __forceinline__ void hx_stage_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// Row tile -> normalised, scaled, split fragments.  Lane (p, h) owns channels 16kc + 8h .. +7 of
-// row p for kc = 0..7 (the B / A operand slots of k-chunk kc).  LayerNorm over the 128 channels =
+// Row tile (raw[2kc], raw[2kc+1] = channels 16kc + 8h .. +7 of this lane's pair row, from hx_zt_read below) -> normalised,
+// scaled, split fragments: the B / A operand slots of k-chunk kc.  LayerNorm over the 128 channels =
 // this lane's 64 + its partner's (lane ^ 32); affine folded into the weights on the host.
-__device__ __forceinline__ void hx_load_rows(float4 (&raw)[16], const float* __restrict__ rowp, int h) {
-#pragma unroll
-    for (int kc = 0; kc < 8; ++kc) {
-        raw[2 * kc] = *reinterpret_cast<const float4*>(rowp + 16 * kc + 8 * h);
-        raw[2 * kc + 1] = *reinterpret_cast<const float4*>(rowp + 16 * kc + 8 * h + 4);
-    }
-}
 __device__ __forceinline__ void hx_norm_split(h8 (&xh)[8], h8 (&xl)[8], float4 (&raw)[16], float sx) {
     float s = 0.f;
 #pragma unroll
@@ -617,12 +610,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_out_hx(
             hx_dma(rw, smb + buf * HX_STAGE_BYTES + p * 1024, lane16, s * HX_STAGE_BYTES + p * 1024);
         }
     };
-    auto row_ptr = [&](int tile) {              // this lane's z row of wave-tile NW tile + wave (clamped: always readable)
-        const int wt = min(tile * NW + wave, n_wtiles - 1);
-        const int st = wt % ntile, i = (wt / ntile) % N, b = wt / (ntile * N);
-        const int pr = min(pl, min(32, N - st * 32) - 1);
-        return z + (((size_t)b * N + i) * N + st * 32 + pr) * 128;
-    };
+    unsigned char* zt = smb + 2 * HX_STAGE_BYTES + 2048 + wave * HX_ZT_BYTES;
     int tile = blockIdx.x;
     issue(0, 0);
     __syncthreads();
@@ -637,13 +625,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_out_hx(
         const int prow0 = (b * N + i) * N + t0;                  // first pair row of the tile
         const bool more = tile + (int)gridDim.x < n_tiles;
         h8 zh[8], zl[8], xh[8], xl[8];
-        {
-            float4 raw[16];
-            hx_load_rows(raw, row_ptr(tile), h);
-            hx_norm_split(zh, zl, raw, sx);
-        }
-        {   // x_cm[((b*128 + c)*NP + i)*NP + t0 + pl], c = 16kc + 8h + e   (t0 + pl < NP always)
-            float4 raw[16];
+        {   // x_cm[((b*128 + c)*NP + i)*NP + t0 + pl], c = 16kc + 8h + e   (t0 + pl < NP always); the z rows come through the
+            // coalesced LDS loader (two halves), the second half's latency is spent on LayerNorm + split of x
+            float4 raw[16], rawz[16];
             const int cs = NP * NP * 4;
             const int vx = (8 * h * NP * NP + pl) * 4;
             const int sxo = ((b * 128 * NP + i) * NP + t0) * 4;
@@ -654,7 +638,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_out_hx(
                 raw[2 * kc + 1].x = hx_load(rx, vx, sxo + (16 * kc + 4) * cs); raw[2 * kc + 1].y = hx_load(rx, vx, sxo + (16 * kc + 5) * cs);
                 raw[2 * kc + 1].z = hx_load(rx, vx, sxo + (16 * kc + 6) * cs); raw[2 * kc + 1].w = hx_load(rx, vx, sxo + (16 * kc + 7) * cs);
             }
+            const int zsoff = prow0 * 512, znv = min(32, N - t0);
+            hx_zt_dma(rz, zt, lane, zsoff, 512, znv, 0); hx_vm_done(); hx_zt_read(rawz, zt, pl, h, 0); hx_lds_done();
+            hx_zt_dma(rz, zt, lane, zsoff, 512, znv, 1);
             hx_norm_split(xh, xl, raw, sx);
+            hx_vm_done(); hx_zt_read(rawz, zt, pl, h, 1);
+            hx_norm_split(zh, zl, rawz, sx);
         }
         const int voff = (4 * h * 128 + pl) * 4;
 #pragma unroll
