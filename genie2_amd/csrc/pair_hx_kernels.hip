@@ -28,7 +28,7 @@ __device__ __forceinline__ float hx_load(rsrc_t r, int voff, int soff) {
 #define HX_ZT_BYTES 8192                                   // per-wave row-tile staging (half a tile: 32 rows x 64 channels)
 #define HX_LDS_BYTES (2 * HX_STAGE_BYTES + 2048 + 8 * HX_ZT_BYTES)
 #ifndef HX_ABL
-#define HX_ABL 0          // developer ablation builds (tools/abl_build.sh); 0 in the product
+#define HX_ABL 0          // developer builds (tools/abl_build.sh): 128 = in-kernel timestamps; 0 in the product
 #endif
 #if HX_ABL & 128          // in-kernel timestamps of every wave of work-group 0 (tools/ts_read.py)
 __device__ unsigned long long g_hx_ts[24][4096];   // [variant * 8 + wave]
@@ -289,27 +289,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_pair_transition_hx
 // vmcnt bookkeeping: per stage a wave issues its LDS-DMA pieces for the next stage first, then
 // exactly 16 stores (dropped ones count too), so `s_waitcnt vmcnt(16)` = "the DMA has landed" without
 // waiting for the stores (vector-memory operations retire in order).
-#if HX_ABL & 512
-#define HX_PROJ_PIECE_A(EG, r, t)  t = EG[r] * cg
-#define HX_PROJ_PIECE_B(EP, r, t, u) do { t = 1.0f + t; u = EP[r] * e_pm; } while (0)
-#else
 #define HX_PROJ_PIECE_A(EG, r, t)  t = __builtin_amdgcn_exp2f(EG[r] * cg)
 #define HX_PROJ_PIECE_B(EP, r, t, u) do { t = __builtin_amdgcn_rcpf(1.0f + t); u = EP[r] * e_pm; } while (0)
-#endif
-#if HX_ABL & 2
-#define HX_PROJ_PIECE_C(r, t, u) do { if (u * t == 123.456f) hx_store_u(e_rd, hx_pack_prod(u, t), e_voff, e_so + (((r) & 3) + 8 * ((r) >> 2)) * sstride); } while (0)
-#else
 #define HX_PROJ_PIECE_C(r, t, u) hx_store_u(e_rd, hx_pack_prod(u, t), e_voff, e_so + (((r) & 3) + 8 * ((r) >> 2)) * sstride)
-#endif
-#if HX_ABL & (32 | 256)
-#define HX_PROJ_REINIT(EP, EG, r) do { } while (0)
-#else
 #define HX_PROJ_REINIT(EP, EG, r) do { EP[r] = sbn[acc_row(r, lane)]; EG[r] = sbn[256 + acc_row(r, lane)]; } while (0)
-#endif
 #define HX_PROJ_STAGE(AP, AG, EP, EG)                                                                              \
     do {                                                                                                           \
         const float* sbn = sbias + ((pass + 1) & 7) * 32;   /* EP / EG become the next pass's accumulators */       \
-        if (HX_ABL & 32) { _Pragma("unroll") for (int r = 0; r < 16; ++r) { AP[r] = sbias[pass * 32 + acc_row(r, lane)]; AG[r] = sbias[256 + pass * 32 + acc_row(r, lane)]; } } \
         h8 ph = hx_frag(stage, 0, 0, lane), pq = hx_frag(stage, 0, 1, lane), gh = hx_frag(stage, 1, 0, lane),     \
            gq = hx_frag(stage, 1, 1, lane);                                                                        \
         _Pragma("unroll") for (int kc = 0; kc < 8; ++kc) {                                                         \
@@ -411,7 +397,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_proj_hx(
                 const float e_pm = pp == 0 ? p_pm : (pp > 2 ? mb : ma);
                 HX_PROJ_STAGE(apA, agA, apB, agB);
                 HX_TS();
-                if (!(HX_ABL & 8)) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); HX_TS(); hx_stage_barrier(); }
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); HX_TS(); hx_stage_barrier();
                 HX_TS();
             }
             {   // odd pass 2pp + 1 -> set B; epilogue of pass 2pp (set A)
@@ -430,7 +416,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_proj_hx(
                 const float e_pm = pp < 2 ? ma : mb;
                 HX_PROJ_STAGE(apB, agB, apA, agA);
                 HX_TS();
-                if (!(HX_ABL & 8)) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); HX_TS(); hx_stage_barrier(); }
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); HX_TS(); hx_stage_barrier();
                 HX_TS();
             }
         }
