@@ -53,3 +53,59 @@ def load_pretrained_model(rootdir, name, epoch):
         print('Missing checkpoint file: ' + ckpt)
         raise SystemExit(0)
     return Genie.load_from_checkpoint(ckpt, config)
+
+
+# ---- training-directory layout (genie/utils/model_io.py:7-137) -----------------------------------------------------
+def get_versions(rootdir, name):
+    """model_io.py:7-25: <rootdir>/<name>/version_<v> directories, ascending."""
+    import glob
+    return sorted(int(d.split('_')[-1]) for d in glob.glob(os.path.join(rootdir, name, 'version_*')))
+
+
+def get_epochs(rootdir, name, version):
+    """model_io.py:27-48: version_<v>/checkpoints/epoch=<e>.ckpt, ascending."""
+    import glob
+    return sorted(int(p.split('=')[-1].split('.')[0])
+                  for p in glob.glob(os.path.join(rootdir, name, 'version_{}'.format(version), 'checkpoints', '*.ckpt')))
+
+
+def load_config(rootdir, name):
+    return Config(os.path.join(rootdir, name, 'configuration'))
+
+
+def load_default_model(rootdir, name):
+    return Genie(load_config(rootdir, name))
+
+
+def load_model(rootdir, name, version=None, epoch=None):
+    """model_io.py:84-137: latest version / epoch by default; an untrained Genie when there is no checkpoint."""
+    versions = get_versions(rootdir, name)
+    if version is None:
+        if not versions:
+            print('No checkpoint available (version)')
+            print('Using default untrained model')
+            return load_default_model(rootdir, name)
+        version = max(versions)
+    else:
+        assert version in versions, 'Missing checkpoint version: {}'.format(version)
+    epochs = get_epochs(rootdir, name, version)
+    if epoch is None:
+        if not epochs:
+            print('No checkpoint available (epoch)')
+            print('Using default untrained model')
+            return load_default_model(rootdir, name)
+        epoch = max(epochs)
+    else:
+        assert epoch in epochs, 'Missing checkpoint epoch: {}'.format(epoch)
+    ckpt = os.path.join(rootdir, name, 'version_{}'.format(version), 'checkpoints', 'epoch={}.ckpt'.format(epoch))
+    print('Loading checkpoint: {}'.format(ckpt))
+    return Genie.load_from_checkpoint(ckpt, config=load_config(rootdir, name))
+
+
+def save_checkpoint(genie, ckpt_filepath, epoch=0, global_step=0):
+    """Write the weights in the layout the reference's Lightning `Genie.load_from_checkpoint(path, config=...)` reads
+    (`state_dict` with `model.`-prefixed Denoiser keys, train.py:35-39): tensors only, loadable with weights_only=True."""
+    os.makedirs(os.path.dirname(os.path.abspath(ckpt_filepath)), exist_ok=True)
+    sd = {'model.' + k: v.detach().cpu() for k, v in genie.model.state_dict().items()}
+    torch.save({'epoch': int(epoch), 'global_step': int(global_step), 'pytorch-lightning_version': 'none',
+                'state_dict': sd}, ckpt_filepath)

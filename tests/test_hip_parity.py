@@ -208,6 +208,38 @@ def test_hx_operand_scaling_follows_the_weights(scale):
     eng.close()
 
 
+@pytest.mark.parametrize('math', MATH_MODES)
+def test_reference_style_initialisation_with_zero_final_layers(math):
+    """The reference initialises every 'final' Linear to zero and gate Linears to (0, 1) (primitives.py:96-160): whole weight
+    matrices are exactly zero, which the load-time operand scales of the split-f16 path must survive (no inf / NaN)."""
+    from genie2_amd.engine import GenieEngine
+    dims = O.small_dims()
+    sd = O.synthetic_state_dict(dims, seed=6)
+    for k in sd:
+        if k.endswith(('linear_z.weight', 'linear_z.bias', 'pair_transition.linear_2.weight', 'pair_transition.linear_2.bias',
+                       'ipa.linear_out.weight', 'ipa.linear_out.bias', 'linear_3.weight', 'linear_3.bias')):
+            sd[k] = torch.zeros_like(sd[k])
+        elif k.endswith(('linear_g.weight', 'linear_a_g.weight', 'linear_b_g.weight')):
+            sd[k] = torch.zeros_like(sd[k])
+        elif k.endswith(('linear_g.bias', 'linear_a_g.bias', 'linear_b_g.bias')):
+            sd[k] = torch.ones_like(sd[k])
+    g = torch.Generator().manual_seed(2)
+    f = O.empty_features([33, 20])
+    trans = 2.5 * torch.randn(2, 33, 3, generator=g)
+    fr = O.prepare_features(f)
+    rots = O.compute_frenet_frames(trans, fr['chain_index'], fr['residue_mask'])
+    ts = torch.tensor([17, 90], dtype=torch.int32)
+    ref = O.denoiser_forward(sd, dims, rots, trans, ts, f, 'closed')
+    eng = GenieEngine(dims, sd, 'cuda:0', math=math)
+    eng.bind_features(f)
+    out = eng.denoise(trans, rots, ts, None, taps=('p', 's_final'))
+    m = fr['residue_mask'].unsqueeze(-1).float()
+    assert torch.isfinite(out['p']).all() and torch.isfinite(out['z']).all()
+    assert mdiff(out['p'], ref['p']) <= 1e-4 * max(1.0, float(ref['p'].abs().max()))
+    assert mdiff(out['z'].cpu() * m, ref['z'] * m) <= 1e-4 * max(1.0, float(ref['z'].abs().max()))
+    eng.close()
+
+
 def test_full_size_n256_matches_oracle_and_batches_are_independent(base_engine, base_weights):
     """N=256 (the metric's length): batch entry 0 against the oracle directly
     (one structure is ~3 s of CPU), then size-independent properties at batch 8:

@@ -183,3 +183,38 @@ def test_two_rank_gloo_path():
     os.unlink(fh.name)
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, e.decode()[-2000:]
+
+
+def test_checkpoint_directory_layouts_round_trip(tmp_path):
+    """genie/utils/model_io.py: pretrained layout (checkpoints/epoch.<E>.ckpt), training layout
+    (version_<v>/checkpoints/epoch=<e>.ckpt, latest by default), Lightning-style state_dict keys."""
+    import shutil
+    import torch
+    from genie.utils import model_io
+    from genie2_amd.diffusion import Genie
+    from genie2_amd.config import Config
+    root = tmp_path / 'runs'
+    (root / 'tiny').mkdir(parents=True)
+    cfg_text = 'name tiny\nnumberOfPairTransformLayers 1\nnumberOfStructureLayers 1\n'
+    (root / 'tiny' / 'configuration').write_text(cfg_text)
+    cfg = Config(str(root / 'tiny' / 'configuration'))
+    g = Genie(cfg)
+    with torch.no_grad():
+        for p in g.model.parameters():
+            p.normal_(0, 0.02)
+    assert model_io.get_versions(str(root), 'tiny') == []
+    fresh = model_io.load_model(str(root), 'tiny')                   # no checkpoint: untrained model
+    assert isinstance(fresh, Genie)
+    model_io.save_checkpoint(g, str(root / 'tiny' / 'version_0' / 'checkpoints' / 'epoch=3.ckpt'), epoch=3)
+    model_io.save_checkpoint(fresh, str(root / 'tiny' / 'version_0' / 'checkpoints' / 'epoch=1.ckpt'), epoch=1)
+    model_io.save_checkpoint(fresh, str(root / 'tiny' / 'version_2' / 'checkpoints' / 'epoch=0.ckpt'))
+    assert model_io.get_versions(str(root), 'tiny') == [0, 2] and model_io.get_epochs(str(root), 'tiny', 0) == [1, 3]
+    ck = torch.load(root / 'tiny' / 'version_0' / 'checkpoints' / 'epoch=3.ckpt', weights_only=True)
+    assert all(k.startswith('model.') for k in ck['state_dict']) and len(ck['state_dict']) == len(g.model.state_dict())
+    got = model_io.load_model(str(root), 'tiny', version=0)          # latest epoch of version 0
+    for k, v in g.model.state_dict().items():
+        assert torch.equal(got.model.state_dict()[k], v), k
+    (root / 'tiny' / 'checkpoints').mkdir()
+    shutil.copy(root / 'tiny' / 'version_0' / 'checkpoints' / 'epoch=3.ckpt', root / 'tiny' / 'checkpoints' / 'epoch.3.ckpt')
+    pre = model_io.load_pretrained_model(str(root), 'tiny', 3)
+    assert torch.equal(pre.model.state_dict()['single_feature_net.linear.weight'], g.model.state_dict()['single_feature_net.linear.weight'])
