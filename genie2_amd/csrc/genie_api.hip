@@ -478,6 +478,14 @@ int genie_prepare_features(genie_handle_t h, genie_stream_t stream, int B, int N
     if (!h->have_weights) { SET_ERR(h, "genie_prepare_features: weights not loaded"); return GENIE_E_STATE; }
     const genie_dims_t& d = h->d;
     if (ipa_attn_lds(d, N) > 160 * 1024) { SET_ERR(h, "N = %d exceeds the attention kernel's LDS budget", N); return GENIE_E_ARG; }
+    {   // the pair kernels address [B,N,N,128] f32 tensors with 32-bit buffer offsets (SGPR soffset + VGPR voffset)
+        const size_t np = (size_t)((N + 31) / 32 * 32);
+        const size_t pair_bytes = (size_t)B * np * np * d.c_p * sizeof(float);
+        if (pair_bytes >= ((size_t)1 << 31)) {
+            SET_ERR(h, "batch %d x N %d: a pair tensor of %zu bytes exceeds the 2 GiB the kernels address; split the batch", B, N, pair_bytes);
+            return GENIE_E_ARG;
+        }
+    }
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     const int NP = (N + 31) / 32 * 32;

@@ -240,6 +240,16 @@ def test_reference_style_initialisation_with_zero_final_layers(math):
     eng.close()
 
 
+def test_oversized_batch_is_refused_not_wrapped(base_engine):
+    """[B,N,N,128] f32 must stay below 2 GiB (32-bit buffer offsets in the pair kernels): asking for more raises
+    instead of wrapping addresses."""
+    from genie2_amd.capi import GenieError
+    f = O.empty_features([256] * 64)
+    with pytest.raises(GenieError, match='split the batch'):
+        base_engine.bind_features(f)
+    base_engine.bind_features(O.empty_features([16]))       # the handle stays usable
+
+
 def test_full_size_n256_matches_oracle_and_batches_are_independent(base_engine, base_weights):
     """N=256 (the metric's length): batch entry 0 against the oracle directly
     (one structure is ~3 s of CPU), then size-independent properties at batch 8:
