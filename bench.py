@@ -144,7 +144,7 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
-    dist = world > 1
+    dist = world > 1 or os.environ.get('GENIE_BENCH_FORCE_DIST') == '1'     # (single-rank rehearsal of the RCCL path)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if dist:
