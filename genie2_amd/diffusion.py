@@ -109,3 +109,16 @@ def save_checkpoint(genie, ckpt_filepath, epoch=0, global_step=0):
     sd = {'model.' + k: v.detach().cpu() for k, v in genie.model.state_dict().items()}
     torch.save({'epoch': int(epoch), 'global_step': int(global_step), 'pytorch-lightning_version': 'none',
                 'state_dict': sd}, ckpt_filepath)
+
+
+def mse(x_pred, x, mask, aggregate=None, eps=1e-10):
+    """genie/utils/loss.py:4-36 (despite the name: masked per-residue L2 error, optionally averaged / summed per sample)."""
+    errors = (eps + torch.sum((x_pred - x) ** 2, dim=-1)) ** 0.5
+    if aggregate is None:
+        return errors * mask
+    if aggregate == 'mean':
+        return torch.sum(errors * mask, dim=-1) / torch.sum(mask, dim=-1)
+    if aggregate == 'sum':
+        return torch.sum(errors * mask, dim=-1)
+    print('Invalid aggregate method: {}'.format(aggregate))
+    raise SystemExit(0)

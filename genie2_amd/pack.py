@@ -160,3 +160,15 @@ BASE_DIMS = dict(
     n_pair_transform_layer=5, c_hidden_mul=128, pair_transition_n=4,
     n_structure_layer=8, n_structure_block=1, c_hidden_ipa=16, n_head_ipa=12, n_qk_point=4, n_v_point=8,
     n_timestep=1000, max_n_res=256, max_n_chain=1)
+
+
+def sinusoidal_encoding(v, N, D):
+    """genie/utils/encoding.py:5-25 for arbitrary index tensors `v` [*] -> [*, D] (the device tables above are
+    this function evaluated on 0..n-1)."""
+    k = torch.arange(1, D + 1, device=v.device)
+    shape = (1,) * v.dim() + (D,)
+    sin_enc = torch.sin(v.unsqueeze(-1) * math.pi / (N ** (2 * k / D)).view(shape))
+    cos_enc = torch.cos(v.unsqueeze(-1) * math.pi / (N ** (2 * (k - 1) / D)).view(shape))
+    enc = sin_enc.clone()
+    enc[..., 0::2] = cos_enc[..., 0::2]
+    return enc

@@ -218,3 +218,25 @@ def test_checkpoint_directory_layouts_round_trip(tmp_path):
     shutil.copy(root / 'tiny' / 'version_0' / 'checkpoints' / 'epoch=3.ckpt', root / 'tiny' / 'checkpoints' / 'epoch.3.ckpt')
     pre = model_io.load_pretrained_model(str(root), 'tiny', 3)
     assert torch.equal(pre.model.state_dict()['single_feature_net.linear.weight'], g.model.state_dict()['single_feature_net.linear.weight'])
+
+
+def test_small_reference_utilities_under_their_import_paths():
+    """genie.utils.encoding / genie.constants.residue / genie.utils.loss: the host-side helpers user code imports."""
+    import torch
+    from conftest import load_golden
+    from genie.utils.encoding import sinusoidal_encoding
+    from genie.constants.residue import RESTYPES, RESTYPE_ORDER, RESTYPE_1_TO_3, RESTYPE_3_TO_1
+    from genie.utils.loss import mse
+    g = load_golden('encoding')
+    for nm, (vmax, N, D) in dict(pos=(256, 256, 256), chain=(4, 1, 64), t1000=(1001, 1000, 512)).items():
+        e = sinusoidal_encoding(torch.arange(vmax, dtype=torch.int32), N, D)
+        assert torch.equal(e[torch.from_numpy(g[nm + '_rows'])], torch.from_numpy(g[nm + '_vals']))      # the reference's own values
+    assert sinusoidal_encoding(torch.zeros(2, 3, dtype=torch.int32), 10, 8).shape == (2, 3, 8)
+    assert ''.join(RESTYPES) == 'ARNDCQEGHILKMFPSTWYV' and RESTYPE_ORDER['V'] == 19
+    assert RESTYPE_1_TO_3['W'] == 'TRP' and RESTYPE_3_TO_1['GLY'] == 'G'
+    x = torch.zeros(2, 3, 3)
+    y = torch.ones(2, 3, 3)
+    m = torch.tensor([[1., 1., 0.], [1., 0., 0.]])
+    e = mse(y, x, m)
+    assert e.shape == (2, 3) and torch.allclose(e[0, :2], torch.full((2,), 3 ** 0.5)) and float(e[0, 2]) == 0.0
+    assert torch.allclose(mse(y, x, m, 'mean'), torch.full((2,), 3 ** 0.5)) and torch.allclose(mse(y, x, m, 'sum'), torch.tensor([2 * 3 ** 0.5, 3 ** 0.5]))
