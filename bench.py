@@ -205,20 +205,29 @@ def main():
         kern = {k: {'ms_per_launch': ms / max(cnt, 1), 'launches_per_step': cnt / P, 'ms_per_step': ms / P}
                 for k, (ms, cnt) in prof.items() if cnt}
         dom = max((k for k in kern if k in flops), key=lambda k: kern[k]['ms_per_step'])
-        launch_s = kern[dom]['ms_per_launch'] * 1e-3
-        nbytes = algorithmic_bytes(dims, B, N)[dom]
-        mfma_flop = flops[dom] * (3.0 if math == 'hx' else 1.0)           # matrix-pipe FLOP per launch
         mfma_peak = PEAK_F16_MFMA_TFLOPS if math == 'hx' else PEAK_FP32_MFMA_TFLOPS
-        t_mfma, t_hbm = mfma_flop / (mfma_peak * 1e12), nbytes / (PEAK_HBM_GBS * 1e9)
-        if t_hbm >= t_mfma:
-            ach = nbytes / launch_s / 1e9
-            roof = {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS}
-        else:
-            ach = mfma_flop / launch_s / 1e12
-            roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': mfma_peak, 'unit': 'TFLOP/s', 'frac': ach / mfma_peak}
-        roof.update({'traffic': measured_traffic(dom, math), 'avg_launch_ms': kern[dom]['ms_per_launch'],
-                     'algorithmic_bytes_per_launch': nbytes, 'algorithmic_flop_per_launch': flops[dom],
-                     'matrix_flop_per_launch': mfma_flop, 'floor_ms': {'hbm': t_hbm * 1e3, 'mfma': t_mfma * 1e3}})
+
+        def price(cls):
+            """Roofline of one pair-stack kernel class: the roof (HBM bytes or matrix FLOP) that takes longer bounds it."""
+            launch_s = kern[cls]['ms_per_launch'] * 1e-3
+            nbytes = algorithmic_bytes(dims, B, N)[cls]
+            mfma_flop = flops[cls] * (3.0 if math == 'hx' else 1.0)            # matrix-pipe FLOP per launch
+            t_mfma, t_hbm = mfma_flop / (mfma_peak * 1e12), nbytes / (PEAK_HBM_GBS * 1e9)
+            if t_hbm >= t_mfma:
+                ach = nbytes / launch_s / 1e9
+                r = {'bound': 'hbm', 'kernel': cls, 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS}
+            else:
+                ach = mfma_flop / launch_s / 1e12
+                r = {'bound': 'mfma', 'kernel': cls, 'achieved': ach, 'peak': mfma_peak, 'unit': 'TFLOP/s', 'frac': ach / mfma_peak}
+            r.update({'traffic': measured_traffic(cls, math), 'avg_launch_ms': kern[cls]['ms_per_launch'],
+                      'algorithmic_bytes_per_launch': nbytes, 'algorithmic_flop_per_launch': flops[cls],
+                      'matrix_flop_per_launch': mfma_flop, 'floor_ms': {'hbm': t_hbm * 1e3, 'mfma': t_mfma * 1e3}})
+            return r
+
+        roof = price(dom)
+        other_roofs = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in price(k).items()
+                           if kk in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms')}
+                       for k in flops if k in kern and k != dom}
         whole = step_flops(dims, B, N) * (K / dt) / 1e12
         out = {
             'metric': 'denoise-steps/sec (N=256, T=1000, batch=8)', 'value': value, 'unit': 'batch-steps/s',
@@ -231,7 +240,7 @@ def main():
                        'parallelism': f'replica per GPU x{world}, no data-path collective'},
             'structure_steps_per_s': value * B,
             'whole_step_tflops': whole,
-            'finite': finite, 'roofline': roof,
+            'finite': finite, 'roofline': roof, 'other_pair_kernel_rooflines': other_roofs,
             'kernels': {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in kern.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
