@@ -85,8 +85,8 @@ __global__ __launch_bounds__(512, 1) void probe(float* out, const float* src, fl
 // wave and iteration, barrier per iteration), plus per group of 6 MFMAs:  LDS = 4 ds_read_b128 operand fragments
 // (used by the MFMAs of the NEXT group),  VAL = the epilogue's VALU (mul, exp2, add, rcp, mul, 2 x fma_mix per output,
 // 2 outputs),  B32 = 4 ds_read_b32 (bias re-initialisation).
-template <bool LDS, bool VAL, bool B32>
-__global__ __launch_bounds__(512, 1) void probe2(float* out, float* dst, int iters, unsigned dst_bytes, long long* cyc) {
+template <bool LDS, bool VAL, bool B32, int WDMA = 0>
+__global__ __launch_bounds__(512, 1) void probe2(float* out, float* dst, int iters, unsigned dst_bytes, long long* cyc, const float* wsrc = nullptr) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[65536];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, dst_bytes, 0x00020000);
@@ -103,6 +103,13 @@ __global__ __launch_bounds__(512, 1) void probe2(float* out, float* dst, int ite
         const unsigned slot = (unsigned)((blockIdx.x * 977u + it) * 8u + wave);
         const int sbase = (int)((slot * 4096u) % (dst_bytes - 65536u)) & ~255;
         const unsigned char* stage = lds + (it & 1) * 32768;
+        if (WDMA) {     // the kernels' weight stage: 4 x 1 KiB LDS-DMA per wave into the other buffer, from an L2-resident image
+            const rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wsrc), 0, 1u << 20, 0x00020000);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rwt, (__attribute__((address_space(3))) void*)(lds + ((it + 1) & 1) * 32768 + (4 * wave + q) * 1024), 16,
+                                                         lane * 16, ((it & 15) * 32 + 4 * wave + q) * 1024, 0, 0);
+        }
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             h8 n0 = f0, n1 = f1, n2 = f2, n3 = f3;
@@ -142,14 +149,14 @@ __global__ __launch_bounds__(512, 1) void probe2(float* out, float* dst, int ite
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
 }
 
-template <bool LDS, bool VAL, bool B32>
-void run2(float* out, float* dst, unsigned db, long long* cyc, const char* name) {
+template <bool LDS, bool VAL, bool B32, int WDMA = 0>
+void run2(float* out, float* dst, unsigned db, long long* cyc, const char* name, const float* wsrc = nullptr) {
     const int iters = 1500;
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    probe2<LDS, VAL, B32><<<256, 512>>>(out, dst, 8, db, cyc);
+    probe2<LDS, VAL, B32, WDMA><<<256, 512>>>(out, dst, 8, db, cyc, wsrc);
     hipDeviceSynchronize();
     hipEventRecord(a);
-    probe2<LDS, VAL, B32><<<256, 512>>>(out, dst, iters, db, cyc);
+    probe2<LDS, VAL, B32, WDMA><<<256, 512>>>(out, dst, iters, db, cyc, wsrc);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     long long h[2048]; hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost);
@@ -184,6 +191,8 @@ int main() {
     run2<false, true, false>(out, dst, db, cyc, "MFMA + stores + epilogue VALU");
     run2<true, true, false>(out, dst, db, cyc, "MFMA + stores + LDS fragments + VALU");
     run2<true, true, true>(out, dst, db, cyc, "MFMA + stores + LDS fragments + VALU + b32");
+    run2<true, true, true, 1>(out, dst, db, cyc, "  ... + weight-stage LDS-DMA (L2 hits)", src);
+    run2<false, false, false, 1>(out, dst, db, cyc, "MFMA + stores + weight-stage LDS-DMA", src);
     hipMemset(src, 0, sb);
     run<0, 2>(out, src, dst, sb, db, cyc, "no loads");
     run<1, 2>(out, src, dst, sb, db, cyc, "every wave: LDS-DMA at top");
