@@ -38,9 +38,15 @@ __device__ unsigned long long g_hx_ts[24][4096];   // [variant * 8 + wave]
 extern "C" int genie_hx_debug_read(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hx_ts), sizeof(unsigned long long) * 24 * 4096);
 }
+#if HX_ABL & 256          // finer stamps: per k-chunk in the projection (tools/ts_kc.py), inside the transition's first GEMM (tools/ts_tr.py)
+#define HX_TS2() HX_TS()
+#else
+#define HX_TS2() do { } while (0)
+#endif
 #else
 #define HX_TS_DECL(variant)
 #define HX_TS() do { } while (0)
+#define HX_TS2() do { } while (0)
 #endif
 
 __device__ __forceinline__ void hx_stage_landed() {
@@ -198,10 +204,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_pair_transition_hx
             }
             if (!LAST) issue(hb + 1, (hb + 1) & 1);
             else if (more) issue(0, 0);
+            HX_TS2();
             const unsigned char* stage = smb + (hb & 1) * HX_STAGE_BYTES;
             f32x16 d;
 #pragma unroll
             for (int r = 0; r < 16; ++r) d[r] = sb1[hb * 32 + acc_row(r, lane)];
+            HX_TS2();
             {
                 h8 wh = hx_frag(stage, 0, 0, lane), wl = hx_frag(stage, 0, 1, lane);
 #pragma unroll
@@ -210,6 +218,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_pair_transition_hx
                     PIPE_FENCE();
                     MFH3(wh, wl, zh[kc], zl[kc], d);
                     PIPE_FENCE();
+                    if (kc == 0 || kc == 3) HX_TS2();
                     wh = nh; wl = nl;
                 }
             }
@@ -309,7 +318,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_pair_transition_hx
             PIPE_FENCE(); MFH(gq, zh[kc], AG); PIPE_FENCE(); HX_PROJ_PIECE_A(EG, 2 * kc + 1, t1);                  \
             PIPE_FENCE(); MFH(gh, zl[kc], AG); PIPE_FENCE(); HX_PROJ_PIECE_B(EP, 2 * kc + 1, t1, u1);              \
             PIPE_FENCE(); MFH(gh, zh[kc], AG); PIPE_FENCE(); HX_PROJ_PIECE_C(2 * kc + 1, t1, u1); HX_PROJ_REINIT(EP, EG, 2 * kc + 1); \
-            PIPE_FENCE();                                                                                          \
+            PIPE_FENCE(); HX_TS2();                                                                                \
             ph = nph; pq = npq; gh = ngh; gq = ngq;                                                                \
         }                                                                                                          \
     } while (0)
