@@ -149,6 +149,84 @@ __global__ __launch_bounds__(512, 1) void probe2(float* out, float* dst, int ite
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
 }
 
+// Third probe: MFMA shape.  The full projection-like stage (stores + LDS fragments + epilogue VALU + bias reads + weight DMA)
+// with every v_mfma_f32_32x32x16_f16 replaced by two v_mfma_f32_16x16x32_f16 (same FLOPs, same operand bytes).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+#define MF16(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+__global__ __launch_bounds__(512, 1) void probe3(float* out, float* dst, int iters, unsigned dst_bytes, long long* cyc, const float* wsrc) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[65536];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, dst_bytes, 0x00020000);
+    const rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wsrc), 0, 1u << 20, 0x00020000);
+    for (int i = threadIdx.x; i < 16384; i += 512) reinterpret_cast<float*>(lds)[i] = 0.001f * (i & 255);
+    __syncthreads();
+    f32x4v c[8];
+    f32x16 e0, e1;
+    for (int i = 0; i < 8; ++i) c[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 16; ++i) { e0[i] = 0.1f * i; e1[i] = 0.2f * i; }
+    h8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.01f * lane + i); b[i] = (_Float16)(0.5f + 0.001f * i); }
+    h8 f0 = a, f1 = a, f2 = a, f3 = a;
+    const float cg = 0.37f, pm = 1.1f;
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        const unsigned slot = (unsigned)((blockIdx.x * 977u + it) * 8u + wave);
+        const int sbase = (int)((slot * 4096u) % (dst_bytes - 65536u)) & ~255;
+        const unsigned char* stage = lds + (it & 1) * 32768;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwt, (__attribute__((address_space(3))) void*)(lds + ((it + 1) & 1) * 32768 + (4 * wave + q) * 1024), 16,
+                                                     lane * 16, ((it & 15) * 32 + 4 * wave + q) * 1024, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const h8 n0 = *reinterpret_cast<const h8*>(stage + (4 * g + 0) * 1024 + lane * 16);
+            const h8 n1 = *reinterpret_cast<const h8*>(stage + (4 * g + 1) * 1024 + lane * 16);
+            const h8 n2 = *reinterpret_cast<const h8*>(stage + (4 * g + 2) * 1024 + lane * 16);
+            const h8 n3 = *reinterpret_cast<const h8*>(stage + (4 * g + 3) * 1024 + lane * 16);
+            float t0v, t1v, u0, u1;
+            unsigned w0, w1;
+            FENCE(); MF16(f1, b, c[0]); MF16(f1, a, c[1]); FENCE(); t0v = __builtin_amdgcn_exp2f(e1[2 * g] * cg);
+            FENCE(); MF16(f0, a, c[2]); MF16(f0, b, c[3]); FENCE(); t0v = __builtin_amdgcn_rcpf(1.0f + t0v); u0 = e0[2 * g] * pm;
+            FENCE(); MF16(f0, b, c[0]); MF16(f0, a, c[1]); FENCE();
+            asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(w0) : "v"(u0), "v"(t0v)); asm("v_fma_mixhi_f16 %0, %1, %2, -%0 op_sel_hi:[0,0,1]" : "+v"(w0) : "v"(u0), "v"(t0v));
+            __builtin_amdgcn_raw_buffer_store_b32(w0, rd, lane * 4, sbase + (2 * g) * 256, 0);
+            e0[2 * g] = reinterpret_cast<const float*>(lds)[(2 * g) * 8 + (lane >> 5)]; e1[2 * g] = reinterpret_cast<const float*>(lds)[256 + (2 * g) * 8 + (lane >> 5)];
+            FENCE(); MF16(f3, b, c[4]); MF16(f3, a, c[5]); FENCE(); t1v = __builtin_amdgcn_exp2f(e1[2 * g + 1] * cg);
+            FENCE(); MF16(f2, a, c[6]); MF16(f2, b, c[7]); FENCE(); t1v = __builtin_amdgcn_rcpf(1.0f + t1v); u1 = e0[2 * g + 1] * pm;
+            FENCE(); MF16(f2, b, c[4]); MF16(f2, a, c[5]); FENCE();
+            asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(w1) : "v"(u1), "v"(t1v)); asm("v_fma_mixhi_f16 %0, %1, %2, -%0 op_sel_hi:[0,0,1]" : "+v"(w1) : "v"(u1), "v"(t1v));
+            __builtin_amdgcn_raw_buffer_store_b32(w1, rd, lane * 4, sbase + (2 * g + 1) * 256, 0);
+            e0[2 * g + 1] = reinterpret_cast<const float*>(lds)[(2 * g + 1) * 8 + (lane >> 5)]; e1[2 * g + 1] = reinterpret_cast<const float*>(lds)[256 + (2 * g + 1) * 8 + (lane >> 5)];
+            FENCE();
+            f0 = n0; f1 = n1; f2 = n2; f3 = n3;
+        }
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += c[i].x + c[i].y + c[i].z + c[i].w;
+    for (int i = 0; i < 16; ++i) s += e0[i] + e1[i];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
+}
+
+void run3(float* out, float* dst, unsigned db, long long* cyc, const float* wsrc) {
+    const int iters = 1500;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    probe3<<<256, 512>>>(out, dst, 8, db, cyc, wsrc);
+    hipDeviceSynchronize();
+    hipEventRecord(a);
+    probe3<<<256, 512>>>(out, dst, iters, db, cyc, wsrc);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    long long h[2048]; hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost);
+    double m = 0; for (int i = 0; i < 2048; ++i) m += h[i];
+    m /= 2048.0 * iters;
+    printf("%-44s %.3f ms  %.0f cycles/iteration (ideal MFMA 3072)  %.2f us/iteration\n", "full stage with 16x16x32 MFMAs (2 per 32x32x16)", ms, m, ms * 1e3 / iters);
+}
+
 template <bool LDS, bool VAL, bool B32, int WDMA = 0>
 void run2(float* out, float* dst, unsigned db, long long* cyc, const char* name, const float* wsrc = nullptr) {
     const int iters = 1500;
@@ -193,6 +271,10 @@ int main() {
     run2<true, true, true>(out, dst, db, cyc, "MFMA + stores + LDS fragments + VALU + b32");
     run2<true, true, true, 1>(out, dst, db, cyc, "  ... + weight-stage LDS-DMA (L2 hits)", src);
     run2<false, false, false, 1>(out, dst, db, cyc, "MFMA + stores + weight-stage LDS-DMA", src);
+    run2<true, true, true, 1>(out, dst, db, cyc, "full stage with 32x32x16 MFMAs (again)", src);
+    run3(out, dst, db, cyc, src);
+    run2<true, true, true, 1>(out, dst, db, cyc, "full stage with 32x32x16 MFMAs (again)", src);
+    run3(out, dst, db, cyc, src);
     hipMemset(src, 0, sb);
     run<0, 2>(out, src, dst, sb, db, cyc, "no loads");
     run<1, 2>(out, src, dst, sb, db, cyc, "every wave: LDS-DMA at top");
