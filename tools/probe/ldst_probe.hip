@@ -85,8 +85,9 @@ __global__ __launch_bounds__(512, 1) void probe(float* out, const float* src, fl
 // wave and iteration, barrier per iteration), plus per group of 6 MFMAs:  LDS = 4 ds_read_b128 operand fragments
 // (used by the MFMAs of the NEXT group),  VAL = the epilogue's VALU (mul, exp2, add, rcp, mul, 2 x fma_mix per output,
 // 2 outputs),  B32 = 4 ds_read_b32 (bias re-initialisation).
-template <bool LDS, bool VAL, bool B32, int WDMA = 0>
-__global__ __launch_bounds__(512, 1) void probe2(float* out, float* dst, int iters, unsigned dst_bytes, long long* cyc, const float* wsrc = nullptr) {
+template <bool LDS, bool VAL, bool B32, int WDMA = 0, bool STRIDE = false, bool ZT = false, bool LATE = false>
+__global__ __launch_bounds__(512, 1) void probe2(float* out, float* dst, int iters, unsigned dst_bytes, long long* cyc, const float* wsrc = nullptr,
+                                                const float* zsrc = nullptr) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[65536];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, dst_bytes, 0x00020000);
@@ -103,6 +104,23 @@ __global__ __launch_bounds__(512, 1) void probe2(float* out, float* dst, int ite
         const unsigned slot = (unsigned)((blockIdx.x * 977u + it) * 8u + wave);
         const int sbase = (int)((slot * 4096u) % (dst_bytes - 65536u)) & ~255;
         const unsigned char* stage = lds + (it & 1) * 32768;
+        auto zt_issue = [&]() {
+            const rsrc_t rzt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(zsrc), 0, 1u << 30, 0x00020000);
+            const int zb = (int)(((slot * 2048u) % ((1u << 30) - (1u << 20))) & ~2047u);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rzt, (__attribute__((address_space(3))) void*)(lds + 49152 + wave * 2048 + q * 1024), 16,
+                                                         (lane >> 4) * 512 + (((lane & 15) ^ (lane >> 4)) << 4), zb + q * 1024, 0, 0);
+        };
+        if (ZT && LATE) { /* issued at the end of the stage, below */ }
+        else if (ZT) {       // two pieces of the next row tile per stage: 4 rows x 256 B each, streaming (HBM misses), per-lane addresses
+            const rsrc_t rzt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(zsrc), 0, 1u << 30, 0x00020000);
+            const int zb = (int)(((slot * 2048u) % ((1u << 30) - (1u << 20))) & ~2047u);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rzt, (__attribute__((address_space(3))) void*)(lds + 49152 + wave * 2048 + q * 1024), 16,
+                                                         (lane >> 4) * 512 + (((lane & 15) ^ (lane >> 4)) << 4), zb + q * 1024, 0, 0);
+        }
         if (WDMA) {     // the kernels' weight stage: 4 x 1 KiB LDS-DMA per wave into the other buffer, from an L2-resident image
             const rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wsrc), 0, 1u << 20, 0x00020000);
 #pragma unroll
@@ -126,19 +144,36 @@ __global__ __launch_bounds__(512, 1) void probe2(float* out, float* dst, int ite
             FENCE(); MFH(f0, b, c0); FENCE();
             if (VAL) { asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(w0) : "v"(u0), "v"(t0v)); asm("v_fma_mixhi_f16 %0, %1, %2, -%0 op_sel_hi:[0,0,1]" : "+v"(w0) : "v"(u0), "v"(t0v)); }
             else w0 = __builtin_bit_cast(unsigned, e0[2 * g]);
-            __builtin_amdgcn_raw_buffer_store_b32(w0, rd, lane * 4, sbase + (2 * g) * 256, 0);
+            if (LATE) {
+                if (g >= 4) {
+                    __builtin_amdgcn_raw_buffer_store_b32(w0, rd, lane * 4, sbase + (4 * (g - 4)) * 256, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(w0 + 1, rd, lane * 4, sbase + (4 * (g - 4) + 1) * 256, 0);
+                }
+            } else if (STRIDE) __builtin_amdgcn_raw_buffer_store_b32(w0, rd, (lane >> 5) * (4 << 18) + (lane & 31) * 4, (int)((slot * 128u + (2 * g) * (8u << 18)) % (dst_bytes - (64u << 18))) & ~127, 0);
+            else __builtin_amdgcn_raw_buffer_store_b32(w0, rd, lane * 4, sbase + (2 * g) * 256, 0);
             if (B32) { e0[2 * g] = reinterpret_cast<const float*>(lds)[(2 * g) * 8 + (lane >> 5)]; e1[2 * g] = reinterpret_cast<const float*>(lds)[256 + (2 * g) * 8 + (lane >> 5)]; }
             FENCE(); MFH(f3, b, c1); FENCE(); if (VAL) t1v = __builtin_amdgcn_exp2f(e1[2 * g + 1] * cg);
             FENCE(); MFH(f2, a, c1); FENCE(); if (VAL) { t1v = __builtin_amdgcn_rcpf(1.0f + t1v); u1 = e0[2 * g + 1] * pm; }
             FENCE(); MFH(f2, b, c1); FENCE();
             if (VAL) { asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(w1) : "v"(u1), "v"(t1v)); asm("v_fma_mixhi_f16 %0, %1, %2, -%0 op_sel_hi:[0,0,1]" : "+v"(w1) : "v"(u1), "v"(t1v)); }
             else w1 = __builtin_bit_cast(unsigned, e0[2 * g + 1]);
-            __builtin_amdgcn_raw_buffer_store_b32(w1, rd, lane * 4, sbase + (2 * g + 1) * 256, 0);
+            if (LATE) {
+                if (g >= 4) {
+                    __builtin_amdgcn_raw_buffer_store_b32(w1, rd, lane * 4, sbase + (4 * (g - 4) + 2) * 256, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(w1 + 1, rd, lane * 4, sbase + (4 * (g - 4) + 3) * 256, 0);
+                }
+            } else if (STRIDE) __builtin_amdgcn_raw_buffer_store_b32(w1, rd, (lane >> 5) * (4 << 18) + (lane & 31) * 4, (int)((slot * 128u + (2 * g + 1) * (8u << 18)) % (dst_bytes - (64u << 18))) & ~127, 0);
+            else __builtin_amdgcn_raw_buffer_store_b32(w1, rd, lane * 4, sbase + (2 * g + 1) * 256, 0);
             if (B32) { e0[2 * g + 1] = reinterpret_cast<const float*>(lds)[(2 * g + 1) * 8 + (lane >> 5)]; e1[2 * g + 1] = reinterpret_cast<const float*>(lds)[256 + (2 * g + 1) * 8 + (lane >> 5)]; }
             FENCE();
             f0 = n0; f1 = n1; f2 = n2; f3 = n3;
         }
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (ZT && LATE) {
+            asm volatile("s_waitcnt vmcnt(18)" ::: "memory");      // previous stage's row-tile pieces + this stage's weights have landed
+            zt_issue();
+        } else {
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -227,14 +262,14 @@ void run3(float* out, float* dst, unsigned db, long long* cyc, const float* wsrc
     printf("%-44s %.3f ms  %.0f cycles/iteration (ideal MFMA 3072)  %.2f us/iteration\n", "full stage with 16x16x32 MFMAs (2 per 32x32x16)", ms, m, ms * 1e3 / iters);
 }
 
-template <bool LDS, bool VAL, bool B32, int WDMA = 0>
+template <bool LDS, bool VAL, bool B32, int WDMA = 0, bool STRIDE = false, bool ZT = false, bool LATE = false>
 void run2(float* out, float* dst, unsigned db, long long* cyc, const char* name, const float* wsrc = nullptr) {
     const int iters = 1500;
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    probe2<LDS, VAL, B32, WDMA><<<256, 512>>>(out, dst, 8, db, cyc, wsrc);
+    probe2<LDS, VAL, B32, WDMA, STRIDE, ZT, LATE><<<256, 512>>>(out, dst, 8, db, cyc, wsrc, wsrc);
     hipDeviceSynchronize();
     hipEventRecord(a);
-    probe2<LDS, VAL, B32, WDMA><<<256, 512>>>(out, dst, iters, db, cyc, wsrc);
+    probe2<LDS, VAL, B32, WDMA, STRIDE, ZT, LATE><<<256, 512>>>(out, dst, iters, db, cyc, wsrc, wsrc);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     long long h[2048]; hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost);
@@ -273,8 +308,11 @@ int main() {
     run2<false, false, false, 1>(out, dst, db, cyc, "MFMA + stores + weight-stage LDS-DMA", src);
     run2<true, true, true, 1>(out, dst, db, cyc, "full stage with 32x32x16 MFMAs (again)", src);
     run3(out, dst, db, cyc, src);
-    run2<true, true, true, 1>(out, dst, db, cyc, "full stage with 32x32x16 MFMAs (again)", src);
-    run3(out, dst, db, cyc, src);
+    run2<true, true, true, 1, true, false>(out, dst, db, cyc, "full stage, channel-strided stores", src);
+    run2<true, true, true, 1, false, true>(out, dst, db, cyc, "full stage, + 2 row-tile DMAs from HBM", src);
+    run2<true, true, true, 1, true, true>(out, dst, db, cyc, "full stage, strided stores + row-tile DMAs", src);
+    run2<true, true, true, 1, false, true, true>(out, dst, db, cyc, "row-tile DMAs after the last store, stores in 2nd half", src);
+    run2<true, true, true, 1, false, false, true>(out, dst, db, cyc, "(stores in 2nd half, no row-tile DMAs)", src);
     hipMemset(src, 0, sb);
     run<0, 2>(out, src, dst, sb, db, cyc, "no loads");
     run<1, 2>(out, src, dst, sb, db, cyc, "every wave: LDS-DMA at top");
