@@ -295,12 +295,20 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_pair_transition_hx
 // MFMAs are a dependent chain, so whatever sits between them in program order is free, and the
 // stores leave at a steady rate instead of in a burst per stage (unpipelined, the matrix pipe
 // and HBM alternated chip-wide: the kernel took the SUM of its MFMA and its memory time).
-// vmcnt bookkeeping: per stage a wave issues its LDS-DMA pieces for the next stage first, then
-// exactly 16 stores (dropped ones count too), so `s_waitcnt vmcnt(16)` = "the DMA has landed" without
-// waiting for the stores (vector-memory operations retire in order).
+// vmcnt bookkeeping: per stage a wave issues its LDS-DMA pieces of the next weight stage first, then
+// exactly 16 stores (dropped ones count too), then (some stages) up to 3 row-tile requests, so
+// `s_waitcnt vmcnt(16)` after the last store = "the weights and the row-tile pieces requested a stage
+// ago have landed" without waiting for the stores (vector-memory operations retire in order).
 #define HX_PROJ_PIECE_A(EG, r, t)  t = __builtin_amdgcn_exp2f(EG[r] * cg)
 #define HX_PROJ_PIECE_B(EP, r, t, u) do { t = __builtin_amdgcn_rcpf(1.0f + t); u = EP[r] * e_pm; } while (0)
-#define HX_PROJ_PIECE_C(r, t, u) hx_store_u(e_rd, hx_pack_prod(u, t), e_voff, e_so + (((r) & 3) + 8 * ((r) >> 2)) * sstride)
+#define HX_PROJ_OFF(r) (e_so + (((r) & 3) + 8 * ((r) >> 2)) * sstride)
+/* the first 8 packed outputs of a stage wait in registers and leave with the last 8: all 16 stores sit in the second half of
+   the stage, the HBM-missing row-tile requests are issued right after the last of them, and a wave's next store is then half a
+   stage + a barrier away -- a store queued behind an unreturned load stalls its wave (tools/probe/ldst_probe: 3.08 -> 2.72 us) */
+#define HX_PROJ_PIECE_C(r, t, u) do { const unsigned wv_ = hx_pack_prod(u, t);                                     \
+        if ((r) < 8) wst[(r)] = wv_;                                                                               \
+        else { hx_store_u(e_rd, wst[(r) - 8], e_voff, HX_PROJ_OFF((r) - 8)); hx_store_u(e_rd, wv_, e_voff, HX_PROJ_OFF(r)); } } while (0)
+#define HX_PROJ_PIECE_C_NOW(r, t, u) hx_store_u(e_rd, hx_pack_prod(u, t), e_voff, HX_PROJ_OFF(r))
 #define HX_PROJ_REINIT(EP, EG, r) do { EP[r] = sbn[acc_row(r, lane)]; EG[r] = sbn[256 + acc_row(r, lane)]; } while (0)
 #define HX_PROJ_STAGE(AP, AG, EP, EG)                                                                              \
     do {                                                                                                           \
@@ -360,6 +368,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_proj_hx(
     issue(0, 0);
     for (int u = threadIdx.x; u < 512; u += NW * 64) sbias[u] = bias[u];
     __syncthreads();
+    unsigned wst[8];
     f32x16 apA, agA, apB, agB;                            // set A: even passes, set B: odd passes
 #pragma unroll
     for (int r = 0; r < 16; ++r) { apB[r] = 0.f; agB[r] = 0.f; apA[r] = sbias[acc_row(r, lane)]; agA[r] = sbias[256 + acc_row(r, lane)]; }
@@ -392,11 +401,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_proj_hx(
             {   // even pass 2pp -> set A; epilogue of pass 2pp - 1 (set B; for pp = 0 the previous tile's pass 7)
                 const int pass = 2 * pp;
                 HX_TS();
-                if (more) {                               // next tile's rows, two DMA instructions per stage; first half -> raw at pass 4
+                if (more) {                               // next tile's rows: first half -> raw at pass 4 (requested at the ends of passes 0..2)
                     if (pp == 0) tile_geom(tile + gridDim.x, n_soff, n_nv);
                     if (pp == 2) { hx_zt_read(raw, zt, pl, h, 0); hx_lds_done(); }
-                    if (pp < 2) hx_zt_dma(rz, zt, lane, n_soff, zstride, n_nv, 0, 4 * pp, 2);
-                    else        hx_zt_dma(rz, zt, lane, n_soff, zstride, n_nv, 1, 4 * (pp - 2), 2);
                 }
                 issue(pass + 1, 1);
                 const unsigned char* stage = smb;
@@ -406,16 +413,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_proj_hx(
                 const float e_pm = pp == 0 ? p_pm : (pp > 2 ? mb : ma);
                 HX_PROJ_STAGE(apA, agA, apB, agB);
                 HX_TS();
-                asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); HX_TS(); hx_stage_barrier();
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // weights of the next stage + the row-tile pieces requested a stage ago
+                if (more) {                               // row-tile requests AFTER the stage's last store: passes 0, 2 -> half 0; 4, 6 -> half 1
+                    if (pp == 0) hx_zt_dma(rz, zt, lane, n_soff, zstride, n_nv, 0, 0, 3);
+                    else if (pp == 1) hx_zt_dma(rz, zt, lane, n_soff, zstride, n_nv, 0, 6, 2);
+                    else if (pp == 2) hx_zt_dma(rz, zt, lane, n_soff, zstride, n_nv, 1, 0, 3);
+                    else hx_zt_dma(rz, zt, lane, n_soff, zstride, n_nv, 1, 6, 2);
+                }
+                HX_TS(); hx_stage_barrier();
                 HX_TS();
             }
             {   // odd pass 2pp + 1 -> set B; epilogue of pass 2pp (set A)
                 const int pass = 2 * pp + 1;
                 HX_TS();
-                if (more) {
-                    if (pp < 2) hx_zt_dma(rz, zt, lane, n_soff, zstride, n_nv, 0, 4 * pp + 2, 2);
-                    else        hx_zt_dma(rz, zt, lane, n_soff, zstride, n_nv, 1, 4 * (pp - 2) + 2, 2);
-                }
                 if (pp < 3) issue(pass + 1, 0);
                 else if (more) issue(0, 0);
                 const unsigned char* stage = smb + HX_STAGE_BYTES;
@@ -425,7 +435,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_proj_hx(
                 const float e_pm = pp < 2 ? ma : mb;
                 HX_PROJ_STAGE(apB, agB, apA, agA);
                 HX_TS();
-                asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); HX_TS(); hx_stage_barrier();
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                if (more) {                               // passes 1 -> half 0, 5 -> half 1 (none after passes 3 and 7: the halves are read next)
+                    if (pp == 0) hx_zt_dma(rz, zt, lane, n_soff, zstride, n_nv, 0, 3, 3);
+                    else if (pp == 2) hx_zt_dma(rz, zt, lane, n_soff, zstride, n_nv, 1, 3, 3);
+                }
+                HX_TS(); hx_stage_barrier();
                 HX_TS();
             }
         }
@@ -444,7 +459,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_proj_hx(
         }
         PIPE_FENCE();           // (the packs are asm: keep them clear of the v_rcp results' forwarding window)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) HX_PROJ_PIECE_C(r, t[r], u[r]);
+        for (int r = 0; r < 16; ++r) HX_PROJ_PIECE_C_NOW(r, t[r], u[r]);
     }
 }
 
