@@ -696,6 +696,18 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_out_hx(
                 asm volatile("" : "+v"(c0), "+v"(c1));
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { a0[r] = c0; a1[r] = c1; }
+                const int h4 = 4 * h;
+                float zp0[16], zp1[16];
+                if (half == 1) {    // zh / zl are dead after the second gate: the residual rows of this half are requested before its GEMM
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rc = (r & 3) + 8 * (r >> 2);
+                        const int so = (prow0 + rc) * 512 + ob * 128;
+                        const int vr = (h4 < nvalid - rc) ? voff : 0x7FFFFFF0;
+                        zp0[r] = hx_load(rz, vr, so);
+                        zp1[r] = hx_load(rz, vr, so + 128);
+                    }
+                }
                 h8 f0 = hx_frag(stage, 0, 0, lane), f0l = hx_frag(stage, 0, 1, lane), f1 = hx_frag(stage, 8, 0, lane),
                    f1l = hx_frag(stage, 8, 1, lane);
 #pragma unroll
@@ -712,7 +724,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_out_hx(
                 hx_stage_landed();
                 // residual + store, 8 rows (16 loads) in flight at a time; rows past the tile's valid pairs belong to
                 // the next line: their offset is pushed out of the buffer (load gives 0, store is dropped)
-                const int h4 = 4 * h;
 #pragma unroll
                 for (int r0 = 0; r0 < 16; r0 += 8) {
                     float zr0[8], zr1[8];
@@ -722,8 +733,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_out_hx(
                         const int rc = ((r0 + q) & 3) + 8 * ((r0 + q) >> 2);
                         const int so = (prow0 + rc) * 512 + ob * 128;
                         vo[q] = (h4 < nvalid - rc) ? voff : 0x7FFFFFF0;
-                        zr0[q] = hx_load(rz, vo[q], so);
-                        zr1[q] = hx_load(rz, vo[q], so + 128);
+                        if (half == 1) { zr0[q] = zp0[r0 + q]; zr1[q] = zp1[r0 + q]; }
+                        else { zr0[q] = hx_load(rz, vo[q], so); zr1[q] = hx_load(rz, vo[q], so + 128); }
                     }
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
