@@ -240,3 +240,24 @@ def test_small_reference_utilities_under_their_import_paths():
     e = mse(y, x, m)
     assert e.shape == (2, 3) and torch.allclose(e[0, :2], torch.full((2,), 3 ** 0.5)) and float(e[0, 2]) == 0.0
     assert torch.allclose(mse(y, x, m, 'mean'), torch.full((2,), 3 ** 0.5)) and torch.allclose(mse(y, x, m, 'sum'), torch.tensor([2 * 3 ** 0.5, 3 ** 0.5]))
+
+
+def test_asm_register_rings_are_not_touched_by_the_compiler(tmp_path):
+    """k_gemm_rows / k_gemm_rows_hx stream weights through registers with asm-issued loads and counted vmcnt waits
+    (csrc/common.h).  tools/check_asm_ring.py audits the compiled ISA: between such a load and the wait that retires
+    it no compiler-scheduled instruction may read or write its destination registers."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available')
+    src = os.path.join(ROOT, 'genie2_amd', 'csrc', 'single_kernels.hip')
+    out = tmp_path / 'single_kernels.s'
+    r = subprocess.run([hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-DGENIE_BUILD', '-S', '--cuda-device-only', '-o', str(out), src],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    chk = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_asm_ring.py'), str(out)], capture_output=True, text=True)
+    assert chk.returncode == 0 and ' 0 violations' in chk.stdout, chk.stdout[-2000:]
+    n_loads = int(chk.stdout.split(':')[-1].split('asm loads')[0])
+    assert n_loads >= 40          # both kernels' rings were actually found
