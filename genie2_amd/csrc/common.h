@@ -198,6 +198,7 @@ struct genie_ctx {
     bool hx;                      // pair-stack GEMMs in split-f16 arithmetic (hx.h); GENIE_MATH=f32 selects the f32-MFMA kernels
     unsigned char* hxdev;         // device allocation of the hx weight images
     HxGemmW hxg[64]; int n_hxg;   // hx images of the row-GEMM weights
+    unsigned hx_launches;         // pair-stack launches so far: its parity picks the tile direction of the next one
     size_t wdev_floats;
     float *single_w;              // packed [384][856]
     float *pij_w;                 // packed [256][384]: linear_s_p_i | linear_s_p_j

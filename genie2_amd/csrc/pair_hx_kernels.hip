@@ -24,6 +24,9 @@ __device__ __forceinline__ float hx_load(rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 #define UNI(x) __builtin_amdgcn_readfirstlane(x)
+// Tile order.  Consecutive pair-stack kernels walk their tiles in OPPOSITE directions (`rev` alternates per launch): what one
+// kernel wrote last is what the next one reads first, while it is still in L2 / the 256-MiB Infinity Cache.
+#define HX_PHYS(t) (rev ? n_tiles - 1 - (t) : (t))
 #define PIPE_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define HX_ZT_BYTES 8192                                   // per-wave row-tile staging (half a tile: 32 rows x 64 channels)
 #define HX_LDS_BYTES (2 * HX_STAGE_BYTES + 2048 + 8 * HX_ZT_BYTES)
@@ -125,7 +128,7 @@ __device__ __forceinline__ void hx_vm_done() { asm volatile("s_waitcnt vmcnt(0)"
 template <int NW>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_pair_transition_hx(
     float* __restrict__ z, const float* __restrict__ rmask, const unsigned char* __restrict__ wimg,
-    const float* __restrict__ b1s, const float* __restrict__ b2s, int N, long long M, int n_hb, float sx, float c1, float c2) {
+    const float* __restrict__ b1s, const float* __restrict__ b2s, int N, long long M, int n_hb, float sx, float c1, float c2, int rev) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
     float* sb1 = reinterpret_cast<float*>(smb + 2 * HX_STAGE_BYTES);
     const int lane = threadIdx.x & 63, wave = UNI(threadIdx.x >> 6);
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_pair_transition_hx
     };
     unsigned char* zt = smb + 2 * HX_STAGE_BYTES + 2048 + wave * HX_ZT_BYTES;
     auto tile_geom = [&](int tile, int& soff, int& nv) {      // wave-tile NW tile + wave (clamped): first row (bytes), valid rows
-        const long long r0 = (long long)min(tile * NW + wave, n_wt - 1) * 32;
+        const long long r0 = (long long)min(HX_PHYS(tile) * NW + wave, n_wt - 1) * 32;
         nv = (int)min((long long)32, M - r0);
         soff = (int)(r0 * 512);
     };
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_pair_transition_hx
     float zres[4][16];
 #pragma unroll 1
     for (; tile < n_tiles; tile += gridDim.x) {
-        const int wt_raw = tile * NW + wave;
+        const int wt_raw = HX_PHYS(tile) * NW + wave;
         const bool act = wt_raw < n_wt;
         const long long row0 = (long long)(act ? wt_raw : n_wt - 1) * 32;
         const int nrows = (int)min((long long)32, M - row0);
@@ -335,7 +338,7 @@ template <bool OUTGOING, int NW>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_proj_hx(
     const float* __restrict__ z, const float* __restrict__ rmask, const unsigned char* __restrict__ wimg,
     const float* __restrict__ bias, unsigned* __restrict__ acm, unsigned* __restrict__ bcm, int N, int NP, int n_wtiles,
-    unsigned cm_bytes, unsigned z_bytes, float sx, float cpa, float cpb, float cg) {
+    unsigned cm_bytes, unsigned z_bytes, float sx, float cpa, float cpb, float cg, int rev) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
     float* sbias = reinterpret_cast<float*>(smb + 2 * HX_STAGE_BYTES);      // [512]
     const int lane = threadIdx.x & 63, wave = UNI(threadIdx.x >> 6);
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_proj_hx(
     const rsrc_t rz = hx_rsrc(z, z_bytes);
     const int zstride = OUTGOING ? 512 : N * 512;         // bytes between consecutive pairs of a tile
     auto tile_geom = [&](int tile, int& soff, int& nv) {  // wave-tile NW tile + wave (clamped): byte offset of its first row, valid rows
-        const int wt = min(tile * NW + wave, n_wtiles - 1);
+        const int wt = min(HX_PHYS(tile) * NW + wave, n_wtiles - 1);
         const int st = wt % ntile, line = (wt / ntile) % N, b = wt / (ntile * N);
         nv = min(32, N - st * 32);
         soff = OUTGOING ? ((b * N + line) * N + st * 32) * 512 : ((b * N + st * 32) * N + line) * 512;
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_proj_hx(
     float p_pm = 0.f;
 #pragma unroll 1
     for (; tile < n_tiles; tile += gridDim.x) {
-        const int wt_raw = tile * NW + wave;
+        const int wt_raw = HX_PHYS(tile) * NW + wave;
         const bool act = wt_raw < n_wtiles;
         const int wt = act ? wt_raw : n_wtiles - 1;      // idle waves shadow the last tile (stores dropped)
         const int st = wt % ntile, line = (wt / ntile) % N, b = wt / (ntile * N);
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_proj_hx(
 #define CX_ROWB 48
 template <int WT>
 __global__ __launch_bounds__(256, 2) void k_trimul_contract_hx(const unsigned* __restrict__ acm, const unsigned* __restrict__ bcm,
-                                                               float* __restrict__ xcm, int NP, int n_mat, unsigned cm_bytes, float cx) {
+                                                               float* __restrict__ xcm, int NP, int n_mat, unsigned cm_bytes, float cx, int rev) {
     constexpr int TM = 64 * WT;
     constexpr int PLANE = TM * CX_ROWB;                 // bytes of one (operand, half) plane
     extern __shared__ __attribute__((aligned(16))) unsigned char smb[];   // [2 buf][A hi | A lo | B hi | B lo]
@@ -492,7 +495,8 @@ __global__ __launch_bounds__(256, 2) void k_trimul_contract_hx(const unsigned* _
     const int slds = lr * CX_ROWB + c4 * 8;
     u32x4 rA[WT], rB[WT];
 
-    auto decode = [&](int w, int& mi, int& i0, int& j0) {       // tile id -> (matrix, tile origin)
+    auto decode = [&](int wl, int& mi, int& i0, int& j0) {      // tile id -> (matrix, tile origin); `rev`: last matrices first
+        const int w = rev ? n_tiles - 1 - wl : wl;
         const int grp = w / (8 * T), rem = w % (8 * T);
         const int tile = rem >> 3;
         mi = grp * 8 + (rem & 7);
@@ -603,7 +607,7 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_out_hx(
     float* __restrict__ z, const float* __restrict__ xcm, const unsigned char* __restrict__ wimg,
     const float* __restrict__ bgs, const float* __restrict__ bzs, int N, int NP, int n_wtiles, unsigned cm_bytes,
-    unsigned z_bytes, float sx, float cg, float cz) {
+    unsigned z_bytes, float sx, float cg, float cz, int rev) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
     const int lane = threadIdx.x & 63, wave = UNI(threadIdx.x >> 6);
     const int h = lane >> 5, pl = lane & 31;
@@ -626,7 +630,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_out_hx(
     __syncthreads();
 #pragma unroll 1
     for (; tile < n_tiles; tile += gridDim.x) {
-        const int wt_raw = tile * NW + wave;
+        const int wt_raw = HX_PHYS(tile) * NW + wave;
         const bool act = wt_raw < n_wtiles;
         const int wt = act ? wt_raw : n_wtiles - 1;
         const int st = wt % ntile, i = (wt / ntile) % N, b = wt / (ntile * N);
@@ -770,7 +774,7 @@ void launch_pair_transition_hx(genie_ctx* h, hipStream_t st, const PairLayerW& w
     const int n_hb = h->d.pair_transition_n * 4;
     const HxTransW& x = w.hx_pt;
     hipLaunchKernelGGL(k_pair_transition_hx<8>, dim3(hx_grid((n_wt + 7) / 8, 8)), dim3(512), HX_LDS_BYTES, st, h->p, h->rmaskf,
-                       x.img, x.b1s, x.b2s, h->N, M, n_hb, x.sx, x.c1, x.c2);
+                       x.img, x.b1s, x.b2s, h->N, M, n_hb, x.sx, x.c1, x.c2, (int)(h->hx_launches++ & 1));
 }
 
 // GENIE_HX_SLICE=n runs the three kernels of a triangle multiplication per slice of n structures, reusing
@@ -801,8 +805,9 @@ void launch_trimul_hx(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgo
         {
             ProfScope ps(h, st, KC_TRIMUL_PROJ);
             const dim3 grid(hx_grid((n_wt + nw - 1) / nw, nw)), block(nw * 64);
+            const int rev = (int)(h->hx_launches++ & 1);
 #define HX_PROJ(OUT, NWV) hipLaunchKernelGGL((k_trimul_proj_hx<OUT, NWV>), grid, block, HX_LDS_BYTES, st, zs, ms, x.img_proj, \
-                                             x.bias_proj, acm, bcm, N, NP, n_wt, cm_bytes, z_bytes, x.sx, x.cpa, x.cpb, x.cg)
+                                             x.bias_proj, acm, bcm, N, NP, n_wt, cm_bytes, z_bytes, x.sx, x.cpa, x.cpb, x.cg, rev)
             if (outgoing) HX_PROJ(true, 8);
             else HX_PROJ(false, 8);
 #undef HX_PROJ
@@ -811,22 +816,23 @@ void launch_trimul_hx(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgo
             ProfScope ps(h, st, KC_TRIMUL_CONTRACT);
             const int BC = nb * h->d.c_hidden_mul;
             const int ncu = hx_num_cu();
+            const int rev = (int)(h->hx_launches++ & 1);
             if (NP >= 128) {
                 const int tiles = (NP + 127) / 128;
                 const int n_tiles = tiles * tiles * ((BC + 7) / 8) * 8;
                 hipLaunchKernelGGL(k_trimul_contract_hx<2>, dim3(n_tiles < 3 * ncu ? n_tiles : 3 * ncu), dim3(256), 2 * 4 * 128 * CX_ROWB, st,
-                                   acm, bcm, h->xcm, NP, BC, cm_bytes, x.cx);
+                                   acm, bcm, h->xcm, NP, BC, cm_bytes, x.cx, rev);
             } else {
                 const int tiles = (NP + 63) / 64;
                 const int n_tiles = tiles * tiles * ((BC + 7) / 8) * 8;
                 hipLaunchKernelGGL(k_trimul_contract_hx<1>, dim3(n_tiles < 4 * ncu ? n_tiles : 4 * ncu), dim3(256), 2 * 4 * 64 * CX_ROWB, st,
-                                   acm, bcm, h->xcm, NP, BC, cm_bytes, x.cx);
+                                   acm, bcm, h->xcm, NP, BC, cm_bytes, x.cx, rev);
             }
         }
         {
             ProfScope ps(h, st, KC_TRIMUL_OUT);
             hipLaunchKernelGGL(k_trimul_out_hx<8>, dim3(hx_grid((n_wt + 7) / 8, 8)), dim3(512), HX_LDS_BYTES, st, zs, h->xcm, x.img_out,
-                               x.bgs, x.bzs, N, NP, n_wt, cm_bytes, z_bytes, x.sx, x.cgo, x.cz);
+                               x.bgs, x.bzs, N, NP, n_wt, cm_bytes, z_bytes, x.sx, x.cgo, x.cz, (int)(h->hx_launches++ & 1));
         }
     }
 }
