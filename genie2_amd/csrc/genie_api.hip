@@ -553,6 +553,7 @@ static int denoise_internal(genie_ctx* h, hipStream_t st, const float* trans, co
     const int ldx = (single_in(d) + 7) / 8 * 8;
     auto d2d = [&](void* dst, const void* src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st); };
 
+    h->hx_launches = 1;      // tile directions alternate from a fixed start: pair_init writes p forwards, the first projection reads it backwards
     launch_scale_copy(h, st, trans, h->trans_w, M * 3, d.rescale);
     HIP_TRY(h, d2d(h->rots_w, rots, (size_t)M * 9 * 4));
 

@@ -178,13 +178,14 @@ __global__ __launch_bounds__(256, 2) void k_trimul_contract(const float* __restr
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ipa_bias(const float* __restrict__ z, const float* __restrict__ wp,
                                                   const float* __restrict__ bias, float* __restrict__ out,
-                                                  int B, int N, int LH) {
+                                                  int B, int N, int LH, int rev) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [128][LDZ]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntile = (N + 127) >> 7;
-    const int st = blockIdx.x % ntile;
-    const int i = (blockIdx.x / ntile) % N;
-    const int b = blockIdx.x / (ntile * N);
+    const int bid = rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;     // opposite to the kernel that wrote p last
+    const int st = bid % ntile;
+    const int i = (bid / ntile) % N;
+    const int b = bid / (ntile * N);
     const int t0 = st * 128;
     const int nvalid = min(128, N - t0);
     const float* src = z + (((size_t)b * N + i) * N + t0) * 128;
@@ -489,7 +490,7 @@ void launch_ipa_bias(genie_ctx* h, hipStream_t st) {
     const int LH = h->d.n_structure_layer * h->d.n_head_ipa;
     const size_t lds = 128 * LDZ * sizeof(float);
     hipLaunchKernelGGL(k_ipa_bias, dim3(h->B * N * ntile), dim3(256), lds, st, h->p, h->ipa_bias_w, h->ipa_bias_b, h->ipa_bias,
-                       h->B, N, LH);
+                       h->B, N, LH, h->hx ? (int)(h->hx_launches & 1) : 0);
 }
 
 void pair_wl_kernels_init();

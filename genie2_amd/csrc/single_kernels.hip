@@ -830,7 +830,10 @@ __global__ __launch_bounds__(512) void k_ipa_attn_q(const float* __restrict__ pr
     float* red = opt + Q * NPT;                 // [4][H][CP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int groups = (N + Q - 1) / Q;
-    const int b = blockIdx.x / groups, i0 = (blockIdx.x % groups) * Q;
+    // odd layers walk the queries backwards: p (268 MB at N = 256, batch 8) is re-read by every layer, and a fixed direction
+    // would evict from the 256-MiB Infinity Cache exactly what the next layer needs first
+    const int bid = (layer & 1) ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+    const int b = bid / groups, i0 = (bid % groups) * Q;
     const int nq = min(Q, N - i0);
     for (int u = tid; u < Q * HC; u += 512) { const int q = u / HC; sq[u] = proj[(size_t)(b * N + min(i0 + q, N - 1)) * ldp + (u - q * HC)]; }
     for (int u = tid; u < Q * NQP; u += 512) { const int q = u / NQP; sqp[u] = qp[(size_t)(b * N + min(i0 + q, N - 1)) * NQP + (u - q * NQP)]; }
