@@ -817,7 +817,7 @@ __global__ __launch_bounds__(512) void k_ipa_attn_q(const float* __restrict__ pr
                                                     const float* __restrict__ bias, const float* __restrict__ z,
                                                     const float* __restrict__ rots, const float* __restrict__ trans,
                                                     const float* __restrict__ rmask, const float* __restrict__ head_w,
-                                                    float* __restrict__ cat, int B, int N, int layer) {
+                                                    float* __restrict__ cat, int B, int N, int layer, int rev) {
     constexpr int CP = 128, HC = H * C, NQP = H * PQ * 3, NPT = H * PV * 3, NCAT = HC + H * PV * 4 + H * CP, HH = H / 2;
     static_assert(H % 2 == 0 && C % 4 == 0 && HC + NPT <= 512, "shape");
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -830,9 +830,9 @@ __global__ __launch_bounds__(512) void k_ipa_attn_q(const float* __restrict__ pr
     float* red = opt + Q * NPT;                 // [4][H][CP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int groups = (N + Q - 1) / Q;
-    // odd layers walk the queries backwards: p (268 MB at N = 256, batch 8) is re-read by every layer, and a fixed direction
-    // would evict from the 256-MiB Infinity Cache exactly what the next layer needs first
-    const int bid = (layer & 1) ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+    // `rev` alternates per layer (starting opposite to the pair-bias kernel's pass): p (268 MB at N = 256, batch 8) is re-read
+    // by every layer, and a fixed direction would evict from the 256-MiB Infinity Cache exactly what the next reader needs first
+    const int bid = rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
     const int b = bid / groups, i0 = (bid % groups) * Q;
     const int nq = min(Q, N - i0);
     for (int u = tid; u < Q * HC; u += 512) { const int q = u / HC; sq[u] = proj[(size_t)(b * N + min(i0 + q, N - 1)) * ldp + (u - q * HC)]; }
@@ -1081,7 +1081,7 @@ void launch_ipa_attn(genie_ctx* h, hipStream_t st, int layer, const float* head_
     if (ipa_is_base(d)) {
         hipLaunchKernelGGL((k_ipa_attn_q<12, 16, 4, 8, IPA_Q>), dim3(h->B * ((h->N + IPA_Q - 1) / IPA_Q)), dim3(512),
                            ipa_attn_t_lds(d, h->N), st, h->proj, ldp, h->kT, h->v, h->qp, h->kpT, h->vp, h->ipa_bias, h->p, h->rots_w,
-                           h->trans_w, h->rmaskf, head_w, h->cat, h->B, h->N, layer);
+                           h->trans_w, h->rmaskf, head_w, h->cat, h->B, h->N, layer, (int)((layer ^ h->hx_launches ^ 1) & 1));
         return;
     }
     hipLaunchKernelGGL(k_ipa_attn, dim3(h->B * h->N), dim3(256), ipa_attn_lds(d, h->N), st, h->proj, ldp, h->kT, h->v, h->qp,
