@@ -85,7 +85,7 @@ __global__ __launch_bounds__(512, 1) void probe(float* out, const float* src, fl
 // wave and iteration, barrier per iteration), plus per group of 6 MFMAs:  LDS = 4 ds_read_b128 operand fragments
 // (used by the MFMAs of the NEXT group),  VAL = the epilogue's VALU (mul, exp2, add, rcp, mul, 2 x fma_mix per output,
 // 2 outputs),  B32 = 4 ds_read_b32 (bias re-initialisation).
-template <bool LDS, bool VAL, bool B32, int WDMA = 0, bool STRIDE = false, bool ZT = false, bool LATE = false>
+template <bool LDS, bool VAL, bool B32, int WDMA = 0, bool STRIDE = false, bool ZT = false, bool LATE = false, int LATEG = 4>
 __global__ __launch_bounds__(512, 1) void probe2(float* out, float* dst, int iters, unsigned dst_bytes, long long* cyc, const float* wsrc = nullptr,
                                                 const float* zsrc = nullptr) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[65536];
@@ -145,9 +145,10 @@ __global__ __launch_bounds__(512, 1) void probe2(float* out, float* dst, int ite
             if (VAL) { asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(w0) : "v"(u0), "v"(t0v)); asm("v_fma_mixhi_f16 %0, %1, %2, -%0 op_sel_hi:[0,0,1]" : "+v"(w0) : "v"(u0), "v"(t0v)); }
             else w0 = __builtin_bit_cast(unsigned, e0[2 * g]);
             if (LATE) {
-                if (g >= 4) {
-                    __builtin_amdgcn_raw_buffer_store_b32(w0, rd, lane * 4, sbase + (4 * (g - 4)) * 256, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(w0 + 1, rd, lane * 4, sbase + (4 * (g - 4) + 1) * 256, 0);
+                if (g >= LATEG) {
+#pragma unroll
+                    for (int qq = 0; qq < 8 / (8 - LATEG); ++qq)
+                        __builtin_amdgcn_raw_buffer_store_b32(w0 + qq, rd, lane * 4, sbase + ((16 / (8 - LATEG)) * (g - LATEG) + qq) * 256, 0);
                 }
             } else if (STRIDE) __builtin_amdgcn_raw_buffer_store_b32(w0, rd, (lane >> 5) * (4 << 18) + (lane & 31) * 4, (int)((slot * 128u + (2 * g) * (8u << 18)) % (dst_bytes - (64u << 18))) & ~127, 0);
             else __builtin_amdgcn_raw_buffer_store_b32(w0, rd, lane * 4, sbase + (2 * g) * 256, 0);
@@ -158,9 +159,10 @@ __global__ __launch_bounds__(512, 1) void probe2(float* out, float* dst, int ite
             if (VAL) { asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(w1) : "v"(u1), "v"(t1v)); asm("v_fma_mixhi_f16 %0, %1, %2, -%0 op_sel_hi:[0,0,1]" : "+v"(w1) : "v"(u1), "v"(t1v)); }
             else w1 = __builtin_bit_cast(unsigned, e0[2 * g + 1]);
             if (LATE) {
-                if (g >= 4) {
-                    __builtin_amdgcn_raw_buffer_store_b32(w1, rd, lane * 4, sbase + (4 * (g - 4) + 2) * 256, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(w1 + 1, rd, lane * 4, sbase + (4 * (g - 4) + 3) * 256, 0);
+                if (g >= LATEG) {
+#pragma unroll
+                    for (int qq = 0; qq < 8 / (8 - LATEG); ++qq)
+                        __builtin_amdgcn_raw_buffer_store_b32(w1 + qq, rd, lane * 4, sbase + ((16 / (8 - LATEG)) * (g - LATEG) + 8 / (8 - LATEG) + qq) * 256, 0);
                 }
             } else if (STRIDE) __builtin_amdgcn_raw_buffer_store_b32(w1, rd, (lane >> 5) * (4 << 18) + (lane & 31) * 4, (int)((slot * 128u + (2 * g + 1) * (8u << 18)) % (dst_bytes - (64u << 18))) & ~127, 0);
             else __builtin_amdgcn_raw_buffer_store_b32(w1, rd, lane * 4, sbase + (2 * g + 1) * 256, 0);
@@ -262,14 +264,14 @@ void run3(float* out, float* dst, unsigned db, long long* cyc, const float* wsrc
     printf("%-44s %.3f ms  %.0f cycles/iteration (ideal MFMA 3072)  %.2f us/iteration\n", "full stage with 16x16x32 MFMAs (2 per 32x32x16)", ms, m, ms * 1e3 / iters);
 }
 
-template <bool LDS, bool VAL, bool B32, int WDMA = 0, bool STRIDE = false, bool ZT = false, bool LATE = false>
+template <bool LDS, bool VAL, bool B32, int WDMA = 0, bool STRIDE = false, bool ZT = false, bool LATE = false, int LATEG = 4>
 void run2(float* out, float* dst, unsigned db, long long* cyc, const char* name, const float* wsrc = nullptr) {
     const int iters = 1500;
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    probe2<LDS, VAL, B32, WDMA, STRIDE, ZT, LATE><<<256, 512>>>(out, dst, 8, db, cyc, wsrc, wsrc);
+    probe2<LDS, VAL, B32, WDMA, STRIDE, ZT, LATE, LATEG><<<256, 512>>>(out, dst, 8, db, cyc, wsrc, wsrc);
     hipDeviceSynchronize();
     hipEventRecord(a);
-    probe2<LDS, VAL, B32, WDMA, STRIDE, ZT, LATE><<<256, 512>>>(out, dst, iters, db, cyc, wsrc, wsrc);
+    probe2<LDS, VAL, B32, WDMA, STRIDE, ZT, LATE, LATEG><<<256, 512>>>(out, dst, iters, db, cyc, wsrc, wsrc);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     long long h[2048]; hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost);
@@ -313,6 +315,8 @@ int main() {
     run2<true, true, true, 1, true, true>(out, dst, db, cyc, "full stage, strided stores + row-tile DMAs", src);
     run2<true, true, true, 1, false, true, true>(out, dst, db, cyc, "row-tile DMAs after the last store, stores in 2nd half", src);
     run2<true, true, true, 1, false, false, true>(out, dst, db, cyc, "(stores in 2nd half, no row-tile DMAs)", src);
+    run2<true, true, true, 1, false, true, true, 6>(out, dst, db, cyc, "row-tile DMAs after the last store, stores in last quarter", src);
+    run2<true, true, true, 1, false, true, true, 4>(out, dst, db, cyc, "row-tile DMAs after the last store, stores in 2nd half", src);
     hipMemset(src, 0, sb);
     run<0, 2>(out, src, dst, sb, db, cyc, "no loads");
     run<1, 2>(out, src, dst, sb, db, cyc, "every wave: LDS-DMA at top");
