@@ -151,7 +151,7 @@ __device__ __forceinline__ void ln_rows_128(float* tile, int ld, const float* __
 enum KernelClass {
     KC_SINGLE_INPUT = 0, KC_GEMM_ROWS, KC_LAYERNORM, KC_PAIR_STATIC, KC_PAIR_INIT,
     KC_TRIMUL_PROJ, KC_TRIMUL_CONTRACT, KC_TRIMUL_OUT, KC_PAIR_TRANSITION,
-    KC_IPA_BIAS, KC_IPA_PREP, KC_IPA_ATTN, KC_BB_UPDATE, KC_P_SAMPLE, KC_MISC, KC_COUNT
+    KC_IPA_BIAS, KC_IPA_PREP, KC_IPA_ATTN, KC_BB_UPDATE, KC_STRUCT_ROWS, KC_P_SAMPLE, KC_MISC, KC_COUNT
 };
 
 // "hx" images (hx.h): weights split in f16 halves, in stage order, + the scales that go with them
@@ -226,6 +226,7 @@ struct genie_ctx {
     // workspace (one allocation, carved)
     void* ws; size_t ws_bytes;
     float *p, *acm, *bcm, *xcm, *pstatic, *ipa_bias;
+    unsigned *pmax;               // bits of max |p| over the pair tensor the IPA layers read (k_ipa_bias -> k_ipa_attn_q)
     float *xsingle, *s0, *s, *s1, *s2, *h1, *h2, *pij, *proj, *cat;
     float *kT, *v, *qp, *kpT, *vp;
     float *rots_w, *trans_w;      // working frames
@@ -254,6 +255,7 @@ void launch_pair_transition(genie_ctx* h, hipStream_t st, const PairLayerW& w);
 void launch_ipa_bias(genie_ctx* h, hipStream_t st);
 void launch_ipa_prep(genie_ctx* h, hipStream_t st);
 void launch_ipa_attn(genie_ctx* h, hipStream_t st, int layer, const float* head_w);
+bool launch_struct_rows(genie_ctx* h, hipStream_t st, const StructLayerW& S, const float* trans_in, float* z_out);
 void launch_bb_update(genie_ctx* h, hipStream_t st, const StructLayerW& w, const float* trans_in,
                       float* z_out);
 void launch_frenet(genie_ctx* h, hipStream_t st, int mode, int step, float scale, float* trans,

@@ -25,7 +25,7 @@ static char g_create_err[512] = "";
 
 static const char* kKernelNames[KC_COUNT] = {
     "single_input", "gemm_rows", "layernorm_rows", "pair_static", "pair_init", "trimul_proj", "trimul_contract",
-    "trimul_out", "pair_transition", "ipa_bias", "ipa_prep", "ipa_attn", "bb_update", "p_sample_frenet", "misc"};
+    "trimul_out", "pair_transition", "ipa_bias", "ipa_prep", "ipa_attn", "bb_update", "struct_rows", "p_sample_frenet", "misc"};
 
 // ------------------------------------------------------------------ profiling
 void prof_begin(genie_ctx* h, hipStream_t st, int cls) {
@@ -508,7 +508,7 @@ int genie_prepare_features(genie_handle_t h, genie_stream_t stream, int B, int N
     want(&h->kT, M * H * C * 4); want(&h->v, M * H * C * 4); want(&h->qp, M * H * Pq * 3 * 4);
     want(&h->kpT, M * H * Pq * 3 * 4); want(&h->vp, M * H * Pv * 3 * 4);
     want(&h->rots_w, M * 9 * 4); want(&h->trans_w, M * 3 * 4); want(&h->loop_z, M * 3 * 4);
-    want(&h->tsteps, (size_t)B * 4); want(&h->rmaskf, M * 4);
+    want(&h->tsteps, (size_t)B * 4); want(&h->rmaskf, M * 4); want(&h->pmax, 4);
     want(&h->f_aatype, M * 20 * 4); want(&h->f_rmask, M * 4); want(&h->f_ridx, M * 4); want(&h->f_cidx, M * 4);
     want(&h->f_pos, M * 3 * 4); want(&h->f_fsm, M); want(&h->f_fstm, P); want(&h->f_ifm, M);
     size_t total = 0;
@@ -588,6 +588,7 @@ static int denoise_internal(genie_ctx* h, hipStream_t st, const float* trans, co
             launch_ipa_prep(h, st);
             launch_ipa_attn(h, st, l, S.head_w);
             launch_gemm_rows(h, st, h->cat, ncat, M, ncat, S.out_w, cs, S.out_b, h->s, cs, nullptr, 0, h->s1, cs);
+            if (launch_struct_rows(h, st, S, last ? trans : nullptr, last ? z_out : nullptr)) continue;
             launch_layernorm_rows(h, st, h->s1, h->s2, M, cs, S.ln_ipa_g, S.ln_ipa_b);
             launch_gemm_rows(h, st, h->s2, cs, M, cs, S.t1_w, cs, S.t1_b, nullptr, 0, nullptr, 1, h->h1, cs);
             launch_gemm_rows(h, st, h->h1, cs, M, cs, S.t2_w, cs, S.t2_b, nullptr, 0, nullptr, 1, h->h2, cs);

@@ -18,8 +18,9 @@
 
 
 // Load 64 pair rows x 128 channels (row t at src + t*row_stride) into tile[64][LDZ].
-__device__ __forceinline__ void load_tile64(float* tile, const float* __restrict__ src, size_t row_stride,
-                                            int nvalid, int tid) {
+template <bool AMAX = false>
+__device__ __forceinline__ float load_tile64(float* tile, const float* __restrict__ src, size_t row_stride,
+                                             int nvalid, int tid) {
     // All eight row loads are issued before the first LDS write (unconditional loads from a
     // clamped row, zeroed afterwards): one HBM round trip per tile instead of eight.
     const int c4 = tid & 31;
@@ -37,6 +38,12 @@ __device__ __forceinline__ void load_tile64(float* tile, const float* __restrict
         if (r >= nvalid) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4*>(tile + r * LDZ + c4 * 4) = v[u];
     }
+    float am = 0.f;                // largest magnitude among this thread's values (AMAX only)
+    if constexpr (AMAX) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) am = fmaxf(fmaxf(am, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+    }
+    return am;
 }
 
 // ---------------------------------------------------------------------------
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void k_trimul_contract(const float* __restr
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ipa_bias(const float* __restrict__ z, const float* __restrict__ wp,
                                                   const float* __restrict__ bias, float* __restrict__ out,
-                                                  int B, int N, int LH, int rev) {
+                                                  int B, int N, int LH, int rev, unsigned* pmax) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [128][LDZ]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntile = (N + 127) >> 7;
@@ -189,12 +196,17 @@ __global__ __launch_bounds__(256) void k_ipa_bias(const float* __restrict__ z, c
     const int t0 = st * 128;
     const int nvalid = min(128, N - t0);
     const float* src = z + (((size_t)b * N + i) * N + t0) * 128;
-    load_tile64(sm, src, 128, nvalid, tid);
+    float am = load_tile64<true>(sm, src, 128, nvalid, tid);
     if (nvalid > 64) {
-        load_tile64(sm + 64 * LDZ, src + (size_t)64 * 128, 128, nvalid - 64, tid);
+        am = fmaxf(am, load_tile64<true>(sm + 64 * LDZ, src + (size_t)64 * 128, 128, nvalid - 64, tid));
     } else {
         for (int u = tid; u < 64 * LDZ / 4; u += 256) reinterpret_cast<float4*>(sm + 64 * LDZ)[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // max |p| of the whole tensor for the attention kernel's f16 split (single_kernels.hip k_ipa_attn_q): this pass is
+    // the one that sees every element before the first IPA layer.  Magnitudes order like their bit patterns.
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+    if (lane == 0 && __float_as_uint(am) > *reinterpret_cast<volatile unsigned*>(pmax)) atomicMax(pmax, __float_as_uint(am));
     __syncthreads();
     const int nbo = (LH + 31) >> 5;
     const int t = wave * 32 + (lane & 31);
@@ -489,8 +501,9 @@ void launch_ipa_bias(genie_ctx* h, hipStream_t st) {
     const int N = h->N, ntile = (N + 127) / 128;
     const int LH = h->d.n_structure_layer * h->d.n_head_ipa;
     const size_t lds = 128 * LDZ * sizeof(float);
+    hipMemsetAsync(h->pmax, 0, sizeof(unsigned), st);
     hipLaunchKernelGGL(k_ipa_bias, dim3(h->B * N * ntile), dim3(256), lds, st, h->p, h->ipa_bias_w, h->ipa_bias_b, h->ipa_bias,
-                       h->B, N, LH, h->hx ? (int)(h->hx_launches & 1) : 0);
+                       h->B, N, LH, h->hx ? (int)(h->hx_launches & 1) : 0, h->pmax);
 }
 
 void pair_wl_kernels_init();

@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256) void k_gemm_rows(const float* __restrict__ A, 
 // ---------------------------------------------------------------------------
 #define GH_ROWB 144          // bytes per row of a 64-k plane of halves (128 + 16 pad: conflict-free b128 reads)
 #define GH_PD 8
+#define GH_AD 4            // activation chunks in flight
 __global__ __launch_bounds__(256) void k_gemm_rows_hx(const float* __restrict__ A, int lda, int M, int K,
                                                       const unsigned char* __restrict__ Wx, int Nout, float inv_sw,
                                                       const float* __restrict__ bias, const float* __restrict__ res, int ldr,
@@ -162,7 +163,9 @@ __global__ __launch_bounds__(256) void k_gemm_rows_hx(const float* __restrict__ 
         wf_issue(wh[s], p);
         wf_issue(wl[s], p + 256);
     }
-    v4f ra0, ra1;
+    // activation chunks are fetched GH_AD = 4 chunks ahead (compile-time slots kc & 3): one chunk is only 12 MFMAs per wave,
+    // far less than an L2 / HBM round trip, and with K = 2112 (IPA output projection) there are 33 of them in a row
+    v4f ra[GH_AD][2];
     auto a_addr = [&](int kc, int u) {
         const int r = min(r0 + lr + 16 * u, M - 1), k = min(kc * 64 + c4 * 4, K - 4);
         return A + (size_t)r * lda + k;
@@ -181,27 +184,33 @@ __global__ __launch_bounds__(256) void k_gemm_rows_hx(const float* __restrict__ 
         *reinterpret_cast<uint2*>(&sa[buf][1][row * GH_ROWB + c4 * 8]) = make_uint2(l01, l23);
         if (c4 == 0) sinv[buf][row] = isc;
     };
-    auto a_store = [&](int kc, int buf) {
+    auto a_store = [&](v4f v0, v4f v1, int kc, int buf) {
         const bool kok = kc * 64 + c4 * 4 < K;
         const v4f z4 = {0.f, 0.f, 0.f, 0.f};
-        split_store((kok && r0 + lr < M) ? ra0 : z4, lr, buf);
-        split_store((kok && r0 + lr + 16 < M) ? ra1 : z4, lr + 16, buf);
+        split_store((kok && r0 + lr < M) ? v0 : z4, lr, buf);
+        split_store((kok && r0 + lr + 16 < M) ? v1 : z4, lr + 16, buf);
     };
-    wf_issue(ra0, a_addr(0, 0));
-    wf_issue(ra1, a_addr(0, 1));
-    wf_wait<0>(ra0, ra1);
-    a_store(0, 0);
+    // chunk c sits in slot c & 3: chunks 0..3 now (0 is consumed at once), chunk kc + 4 at the start of chunk kc
+#pragma unroll
+    for (int c = 0; c < GH_AD; ++c) {
+        wf_issue(ra[c][0], a_addr(min(c, nkc - 1), 0));
+        wf_issue(ra[c][1], a_addr(min(c, nkc - 1), 1));
+    }
+    wf_wait<2 * (GH_AD - 1)>(ra[0][0], ra[0][1]);
+    a_store(ra[0][0], ra[0][1], 0, 0);
     __syncthreads();
 
     f32x16 acc = zero16();
     const int foff = (lane & 31) * GH_ROWB + (lane >> 5) * 16;
-    // chunk body with a COMPILE-TIME ring half (slots 4 PAR .. 4 PAR + 3): an asm load into a dynamically indexed register
-    // array would land in a temporary the compiler has already copied from
-    auto chunk = [&](int kc, auto par_tag) {
-        constexpr int PAR = decltype(par_tag)::value;
-        const int kcn = min(kc + 1, nkc - 1);            // last chunk: harmless re-load keeps the counts uniform
-        wf_issue(ra0, a_addr(kcn, 0));
-        wf_issue(ra1, a_addr(kcn, 1));
+    // chunk body with COMPILE-TIME slots (weight ring half 4 PAR .. 4 PAR + 3, activation slots): an asm load into a dynamically
+    // indexed register array would land in a temporary the compiler has already copied from
+    auto chunk = [&](int kc, auto slot_tag, auto first_tag) {
+        constexpr int SL = decltype(slot_tag)::value, PAR = SL & 1, NX = (SL + 1) & (GH_AD - 1);
+        constexpr bool FIRST = decltype(first_tag)::value;          // kc = SL (the first group of four)
+        const int kcn = min(kc + 1, nkc - 1);            // last chunk: harmless re-split keeps the barrier count uniform
+        // slot SL held chunk kc, split at the end of chunk kc - 1: free for chunk kc + 4
+        wf_issue(ra[SL][0], a_addr(min(kc + GH_AD, nkc - 1), 0));
+        wf_issue(ra[SL][1], a_addr(min(kc + GH_AD, nkc - 1), 1));
         const unsigned char* cur = &sa[PAR][0][0] + foff;
         f32x16 part = zero16();
 #pragma unroll
@@ -225,14 +234,23 @@ __global__ __launch_bounds__(256) void k_gemm_rows_hx(const float* __restrict__ 
                 acc[4 * g + 2] = fmaf(part[4 * g + 2], iv.z, acc[4 * g + 2]); acc[4 * g + 3] = fmaf(part[4 * g + 3], iv.w, acc[4 * g + 3]);
             }
         }
-        wf_wait<GH_PD>(ra0, ra1);
-        a_store(kcn, PAR ^ 1);
+        // chunk kc + 1 (slot NX) was issued at the start of chunk kc - 3: younger = 8 refills there + 3 x (2 + 8) since;
+        // chunks 1..3 were issued before the loop: younger = chunks kc + 2 .. 3 (2 loads each) + (kc + 1) x (2 + 8)
+        constexpr int YOUNGER = (FIRST && SL < GH_AD - 1) ? 2 * (GH_AD - 2 - SL) + 10 * (SL + 1) : 8 + 10 * (GH_AD - 1);
+        wf_wait<YOUNGER>(ra[NX][0], ra[NX][1]);
+        a_store(ra[NX][0], ra[NX][1], kcn, PAR ^ 1);
         __syncthreads();
     };
-    for (int kc = 0; kc < nkc; kc += 2) {
-        chunk(kc, std::integral_constant<int, 0>{});
-        if (kc + 1 < nkc) chunk(kc + 1, std::integral_constant<int, 1>{});
-    }
+    auto group = [&](int kc, auto first_tag) {
+        chunk(kc, std::integral_constant<int, 0>{}, first_tag);
+        if (kc + 1 < nkc) chunk(kc + 1, std::integral_constant<int, 1>{}, first_tag);
+        if (kc + 2 < nkc) chunk(kc + 2, std::integral_constant<int, 2>{}, first_tag);
+        if (kc + 3 < nkc) chunk(kc + 3, std::integral_constant<int, 3>{}, first_tag);
+    };
+    group(0, std::true_type{});
+    for (int kc = 4; kc < nkc; kc += 4) group(kc, std::false_type{});
+#pragma unroll
+    for (int c = 0; c < GH_AD; ++c) wf_wait<0>(ra[c][0], ra[c][1]);
 #pragma unroll
     for (int s = 0; s < GH_PD; ++s) wf_wait<0>(wh[s], wl[s]);
     if (!active) return;
@@ -703,6 +721,245 @@ __global__ __launch_bounds__(256) void k_bb_update(const float* __restrict__ s, 
 }
 
 // ---------------------------------------------------------------------------
+// Row-local tail of a structure layer in ONE launch (hx arithmetic, c_s = 32 NW):
+//   s2 = LN_ipa(s1);  s = LN_tr(s2 + W3 relu(W2 relu(W1 s2)));  frames <- frames o BackboneUpdate(s)
+// (structure_net.py:108-116, structure_transition.py:34-70, backbone_update.py:40-66).  Everything between the IPA output
+// projection and the next layer's input projection touches one residue at a time, and at B N = 2048 rows each of the six
+// launches it replaces (three Linears, two LayerNorms, the frame update) was all fixed latency (22 + 22 + 22 + 6 + 6 + 7 us).
+// A work-group owns 32 rows and NW waves; wave w owns output columns 32w..32w+31 of every Linear.  Activations stay in two
+// f32 LDS tiles; each Linear is the k_gemm_rows_hx loop (same block-floating-point split per (row, 64-wide K chunk), same
+// weight-unit ring, same accumulation order -- results are bit-identical to the separate launches) with its A chunks split
+// out of the LDS tile instead of HBM, and writes its result tile in place once the last chunk has been split.
+// ---------------------------------------------------------------------------
+#define SR_PD 4
+#define SR_LD 388            // floats per row of an activation tile (384 + 4: the two half-waves of a D store hit disjoint banks)
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_struct_rows_hx(
+    // (parameters of later stages are deliberately not __restrict__: hipcc would hoist their loads -- 60 registers of LayerNorm
+    //  and BackboneUpdate weights -- to the top of the kernel, across the barriers, and spill the GEMM loop)
+    const float* __restrict__ x, const float* g1, const float* be1, const unsigned char* __restrict__ W1, float i1, const float* b1,
+    const unsigned char* __restrict__ W2, float i2, const float* b2, const unsigned char* __restrict__ W3, float i3, const float* b3,
+    const float* g2, const float* be2, const float* bbw, const float* bbb, float* s_out, float* rots, float* trans, int M,
+    const float* trans_in, float* z_out, float inv_rescale, int nrb) {
+    constexpr int C = NW * 32, NT = NW * 64, KC = C / 16, NKC = C / 64;
+    static_assert(C % 64 == 0 && NT >= 512 && NT <= 1024 && C + 4 <= SR_LD, "shape");
+    extern __shared__ __attribute__((aligned(16))) float srm[];
+    float* T0 = srm;
+    float* T1 = T0 + 32 * SR_LD;
+    unsigned char* sa = reinterpret_cast<unsigned char*>(T1 + 32 * SR_LD);       // [buffer][hi | lo][32 * GH_ROWB]
+    float* sinv = reinterpret_cast<float*>(sa + 4 * 32 * GH_ROWB);               // [buffer][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * 32;
+    const int lr = tid >> 4, c4 = tid & 15;                                      // splitter: threads 0..511 = 32 rows x 16 float4
+    const bool splitter = tid < 512;
+
+    if ((int)blockIdx.x >= nrb) {
+        // The layer's three weight images (1.7 MB) were last used a whole denoiser step ago: they come from HBM, and a row
+        // work-group streaming them through its small register ring would pay that latency chunk after chunk.  The CUs this
+        // launch leaves idle pull them into L2 instead: work-groups are dealt round-robin to the 8 XCDs (one L2 each), so
+        // prefetcher pf = 8 slice + xcd reads slice `slice` of every image into the L2 of its own XCD.
+        const int pf = (int)blockIdx.x - nrb, nsl = max(1, (int)(gridDim.x - nrb) >> 3), slice = min(pf >> 3, nsl - 1);
+        constexpr int IMG = KC * NW * 2048;
+        const unsigned char* imgs[3] = {W1, W2, W3};
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+            for (int o = slice * NT * 16 + tid * 16; o < IMG; o += nsl * NT * 16) {
+                const float4 v = *reinterpret_cast<const float4*>(imgs[w] + o);
+                asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+            }
+        return;
+    }
+
+    // weight units through a wave-uniform base (SGPR pair) + one lane offset; ring of SR_PD = 4 units (one chunk ahead: three
+    // waves per SIMD cover an L2 round trip).  The first units of a Linear are issued before the stage that precedes it.
+    const unsigned loff = lane * 16;
+    const int wsel = __builtin_amdgcn_readfirstlane(wave);
+    v4f wh[SR_PD], wl[SR_PD];
+    auto unit_issue = [&](const unsigned char* wb, v4f& hi, v4f& lo, int u) {
+        const unsigned char* p = wb + (size_t)min(u, KC - 1) * 2048;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(hi) : "v"(loff), "s"(p) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(lo) : "v"(loff), "s"(p) : "memory");
+    };
+    auto ring_fill = [&](const unsigned char* Wx) {
+        const unsigned char* wb = Wx + (size_t)wsel * KC * 2048;
+#pragma unroll
+        for (int u = 0; u < SR_PD; ++u) unit_issue(wb, wh[u], wl[u], u);
+    };
+    ring_fill(W1);
+
+    for (int u = tid; u < 32 * (C / 4); u += NT) {
+        const int r = u / (C / 4), q = u - r * (C / 4);
+        *reinterpret_cast<float4*>(T0 + r * SR_LD + q * 4) =
+            *reinterpret_cast<const float4*>(x + (size_t)min(r0 + r, M - 1) * C + q * 4);
+    }
+    __syncthreads();
+
+    // nn.LayerNorm of the tile's rows in place (k_layernorm_rows' arithmetic: one wave per row, same lane -> column map)
+    auto layernorm = [&](float* T, const float* g, const float* bta, float* gout) {
+        for (int r = wave; r < 32; r += NW) {
+            float v[C / 64];
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < C / 64; ++q) { v[q] = T[r * SR_LD + lane + 64 * q]; sum += v[q]; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            const float mean = sum / (float)C;
+            float ss = 0.f;
+#pragma unroll
+            for (int q = 0; q < C / 64; ++q) { const float d = v[q] - mean; ss += d * d; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+            const float rstd = 1.0f / sqrtf(ss / (float)C + GENIE_LN_EPS);
+#pragma unroll
+            for (int q = 0; q < C / 64; ++q) {
+                const int c = lane + 64 * q;
+                const float y = (v[q] - mean) * rstd * g[c] + bta[c];
+                T[r * SR_LD + c] = y;
+                if (gout && r0 + r < M) gout[(size_t)(r0 + r) * C + c] = y;
+            }
+        }
+        __syncthreads();
+    };
+
+    // one LDS address per thread, everything else as instruction offsets (registers are what this kernel is short of)
+    unsigned char* const sdst = sa + lr * GH_ROWB + c4 * 8;
+    float* const sidst = sinv + lr;
+    const int aoff = lr * SR_LD + c4 * 4;
+    auto dpp_max = [](float m, auto ctrl_tag) {
+        constexpr int CTRL = decltype(ctrl_tag)::value;
+        return fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), CTRL, 0xf, 0xf, false)));
+    };
+    auto split_store = [&](float4 v, auto buf_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        m = dpp_max(m, std::integral_constant<int, 0xB1>{});       // quad_perm [1,0,3,2]
+        m = dpp_max(m, std::integral_constant<int, 0x4E>{});       // quad_perm [2,3,0,1]
+        m = dpp_max(m, std::integral_constant<int, 0x124>{});      // row_ror:4
+        m = dpp_max(m, std::integral_constant<int, 0x128>{});      // row_ror:8  -> largest |a| of the row's 64-wide chunk (16 lanes)
+        const int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 255u);
+        const bool tiny = e < 16;
+        const float sc = tiny ? 1.0f : __builtin_bit_cast(float, (unsigned)(268 - e) << 23);
+        const float isc = tiny ? 1.0f : __builtin_bit_cast(float, (unsigned)(e - 14) << 23);
+        unsigned h01, l01, h23, l23;
+        hx_split2(v.x, v.y, sc, h01, l01);
+        hx_split2(v.z, v.w, sc, h23, l23);
+        *reinterpret_cast<uint2*>(sdst + (BUF * 2 + 0) * 32 * GH_ROWB) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(sdst + (BUF * 2 + 1) * 32 * GH_ROWB) = make_uint2(l01, l23);
+        if (c4 == 0) sidst[BUF * 32] = isc;
+    };
+
+    // out = act(A W^T inv_sw + bias) (+ res), tiles in LDS; `out` may alias A
+    auto linear = [&](const float* A, const unsigned char* __restrict__ Wx, const unsigned char* Wnext, float inv_sw,
+                      const float* bias, bool relu, const float* res, float* out) {
+        const unsigned char* wb = Wx + (size_t)wsel * KC * 2048;
+        if (splitter) split_store(*reinterpret_cast<const float4*>(A + aoff), std::integral_constant<int, 0>{});
+        __syncthreads();
+        f32x16 acc = zero16();
+        const int foff = (lane & 31) * GH_ROWB + (lane >> 5) * 16;
+        auto chunk = [&](int kc, auto par_tag) {
+            constexpr int PAR = decltype(par_tag)::value;
+            const int kcn = min(kc + 1, NKC - 1);
+            const unsigned char* cur = sa + PAR * 2 * 32 * GH_ROWB + foff;
+            f32x16 part = zero16();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const h8 ah = *reinterpret_cast<const h8*>(cur + q * 32);
+                const h8 al = *reinterpret_cast<const h8*>(cur + 32 * GH_ROWB + q * 32);
+                wf_wait<2 * SR_PD - 2>(wh[q], wl[q]);                           // younger: the 3 other ring units
+                const h8 bh = __builtin_bit_cast(h8, wh[q]), bl = __builtin_bit_cast(h8, wl[q]);
+                MFH3(ah, al, bh, bl, part);
+                __builtin_amdgcn_sched_barrier(0);
+                unit_issue(wb, wh[q], wl[q], kc * 4 + q + SR_PD);
+            }
+            {
+                const float* si = sinv + PAR * 32 + 4 * (lane >> 5);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 iv = *reinterpret_cast<const float4*>(si + 8 * g);
+                    acc[4 * g] = fmaf(part[4 * g], iv.x, acc[4 * g]); acc[4 * g + 1] = fmaf(part[4 * g + 1], iv.y, acc[4 * g + 1]);
+                    acc[4 * g + 2] = fmaf(part[4 * g + 2], iv.z, acc[4 * g + 2]); acc[4 * g + 3] = fmaf(part[4 * g + 3], iv.w, acc[4 * g + 3]);
+                }
+            }
+            if (splitter) split_store(*reinterpret_cast<const float4*>(A + kcn * 64 + aoff), std::integral_constant<int, PAR ^ 1>{});
+            __syncthreads();
+        };
+#pragma unroll 1
+        for (int kc = 0; kc < NKC; kc += 2) {
+            chunk(kc, std::integral_constant<int, 0>{});
+            if (kc + 1 < NKC) chunk(kc + 1, std::integral_constant<int, 1>{});
+        }
+#pragma unroll
+        for (int u = 0; u < SR_PD; ++u) wf_wait<0>(wh[u], wl[u]);
+        if (Wnext) ring_fill(Wnext);
+        // every split of A is done (last barrier above): the result may overwrite it
+        const int col = wave * 32 + (lane & 31);
+        const float bc = bias[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, lane);
+            float v = fmaf(acc[r], inv_sw, bc);
+            if (relu) v = fmaxf(v, 0.f);
+            if (res) v += res[row * SR_LD + col];
+            out[row * SR_LD + col] = v;
+        }
+        __syncthreads();
+    };
+
+    layernorm(T0, g1, be1, nullptr);                      // T0 = s2
+    linear(T0, W1, W2, i1, b1, true, nullptr, T1);
+    linear(T1, W2, W3, i2, b2, true, nullptr, T1);
+    linear(T1, W3, nullptr, i3, b3, false, T0, T1);
+    layernorm(T1, g2, be2, s_out);                        // T1 = s
+
+    // BackboneUpdate + frame composition (k_bb_update's arithmetic), one wave per row
+    for (int r = wave; r < 32; r += NW) {
+        const int row = r0 + r;
+        if (row >= M) continue;
+        float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int c = lane; c < C; c += 64) {
+            const float xv = T1[r * SR_LD + c];
+#pragma unroll
+            for (int o = 0; o < 6; ++o) acc[o] += xv * bbw[o * C + c];
+        }
+#pragma unroll
+        for (int o = 0; o < 6; ++o) {
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) acc[o] += __shfl_xor(acc[o], sft);
+            acc[o] += bbb[o];
+        }
+        if (lane == 0) {
+            const float qb = acc[0], qc = acc[1], qd = acc[2];
+            const float den = sqrtf(((qb * qb + qc * qc) + qd * qd) + 1.0f);
+            const float a = 1.0f / den, bq = qb / den, c = qc / den, d = qd / den;
+            float U[9];
+            U[0] = a * a + bq * bq - c * c - d * d; U[1] = 2 * bq * c - 2 * a * d;          U[2] = 2 * bq * d + 2 * a * c;
+            U[3] = 2 * bq * c + 2 * a * d;          U[4] = a * a - bq * bq + c * c - d * d; U[5] = 2 * c * d - 2 * a * bq;
+            U[6] = 2 * bq * d - 2 * a * c;          U[7] = 2 * c * d + 2 * a * bq;          U[8] = a * a - bq * bq - c * c + d * d;
+            float* R = rots + (size_t)row * 9;
+            float* t = trans + (size_t)row * 3;
+            float Rn[9], rr[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) rr[k] = R[k];
+#pragma unroll
+            for (int xx = 0; xx < 3; ++xx)
+#pragma unroll
+                for (int y = 0; y < 3; ++y) Rn[xx * 3 + y] = rr[xx * 3 + 0] * U[0 * 3 + y] + rr[xx * 3 + 1] * U[1 * 3 + y] + rr[xx * 3 + 2] * U[2 * 3 + y];
+            const float tx = rr[0] * acc[3] + rr[1] * acc[4] + rr[2] * acc[5] + t[0];
+            const float ty = rr[3] * acc[3] + rr[4] * acc[4] + rr[5] * acc[5] + t[1];
+            const float tz = rr[6] * acc[3] + rr[7] * acc[4] + rr[8] * acc[5] + t[2];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) R[k] = Rn[k];
+            t[0] = tx; t[1] = ty; t[2] = tz;
+            if (z_out) {
+                z_out[(size_t)row * 3 + 0] = trans_in[(size_t)row * 3 + 0] - tx * inv_rescale;
+                z_out[(size_t)row * 3 + 1] = trans_in[(size_t)row * 3 + 1] - ty * inv_rescale;
+                z_out[(size_t)row * 3 + 2] = trans_in[(size_t)row * 3 + 2] - tz * inv_rescale;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Reverse-loop update + Frenet frames, one work-group per structure
 // (sampler/base.py:249-282, utils/geo_utils.py:21-85).
 //   mode 0: frames of `trans` only.
@@ -810,16 +1067,26 @@ __global__ void k_scale_copy(const float* __restrict__ in, float* __restrict__ o
 // L2 bandwidth at 163 us) by Q.  Logits: thread = (j, half of the heads); o / o_pt: thread = output
 // column, Q accumulators; o_pair: the Q p-rows are streamed one after the other.
 // ---------------------------------------------------------------------------
-template <int H, int C, int PQ, int PV, int Q>
+//
+// MF = 1 (hx arithmetic): o_pair[h][c] = sum_j a[h][j] p[j][c] runs on the matrix pipe.  Wave w owns query w>>1 and
+// channel half w&1: per 32 values of j one v_mfma_f32_16x16x32_f16 triple per 16-channel block, A = the attention
+// weights (12 heads padded to 16 rows, scaled by 2^14), B = p split into f16 halves under ONE power-of-two scale for
+// the whole tensor (`pmax` = max |p|, left by k_ipa_bias, which reads all of p just before the first layer).  A lane's
+// dwordx4 load carries channels 4m..4m+3 of row j = j0 + 8g + e (m = lane&15, g = lane>>4): register r of the eight
+// loads e = 0..7 is exactly the B fragment of the block holding channels {4m + r}, so the stream needs no LDS and no
+// shuffles, and the accumulators of the four blocks form the float4 a lane stores.  No cross-wave reduction, no barrier.
+template <int H, int C, int PQ, int PV, int Q, int MF>
 __global__ __launch_bounds__(512) void k_ipa_attn_q(const float* __restrict__ proj, int ldp, const float* __restrict__ kT,
                                                     const float* __restrict__ v, const float* __restrict__ qp,
                                                     const float* __restrict__ kpT, const float* __restrict__ vp,
                                                     const float* __restrict__ bias, const float* __restrict__ z,
                                                     const float* __restrict__ rots, const float* __restrict__ trans,
                                                     const float* __restrict__ rmask, const float* __restrict__ head_w,
-                                                    float* __restrict__ cat, int B, int N, int layer, int rev) {
+                                                    float* __restrict__ cat, int B, int N, int layer, int rev,
+                                                    const unsigned* __restrict__ pmax) {
     constexpr int CP = 128, HC = H * C, NQP = H * PQ * 3, NPT = H * PV * 3, NCAT = HC + H * PV * 4 + H * CP, HH = H / 2;
     static_assert(H % 2 == 0 && C % 4 == 0 && HC + NPT <= 512, "shape");
+    static_assert(!MF || (H <= 16 && Q == 4), "matrix-pipe o_pair: 8 waves = 4 queries x 2 channel halves");
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int NP8 = (N + 7) & ~7;
     float* att = sm;                            // [Q][H][NP8], zero padded
@@ -827,7 +1094,7 @@ __global__ __launch_bounds__(512) void k_ipa_attn_q(const float* __restrict__ pr
     float* sqp = sq + Q * HC;                   // [Q][NQP]
     float* shw = sqp + Q * NQP;                 // [H] (16 reserved)
     float* opt = shw + 16;                      // [Q][NPT]
-    float* red = opt + Q * NPT;                 // [4][H][CP]
+    float* red = opt + Q * NPT;                 // [4][H][CP]   (MF = 0 only)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int groups = (N + Q - 1) / Q;
     // `rev` alternates per layer (starting opposite to the pair-bias kernel's pass): p (268 MB at N = 256, batch 8) is re-read
@@ -935,6 +1202,62 @@ __global__ __launch_bounds__(512) void k_ipa_attn_q(const float* __restrict__ pr
             }
         }
     }
+    if constexpr (MF) {
+        const int q = wave >> 1, hc = wave & 1, m = lane & 15, g = lane >> 4;
+        if (q < nq) {
+            const int row = b * N + i0 + q;
+            // p S_p in [2^13, 2^14) at the tensor's largest magnitude; a 2^14 <= 2^14
+            const int ex = min(max((int)((*pmax >> 23) & 0xff), 28), 254);
+            const float sp = __uint_as_float((unsigned)(267 - ex) << 23);          // 2^(13 - (ex - 127))
+            const float inv = __uint_as_float((unsigned)(ex - 27) << 23);          // 1 / (sp 2^14)
+            const float sa = (m < H) ? 16384.0f : 0.0f;                            // rows 12..15 of the A tile are padding
+            const float* zr = z + ((size_t)row * N) * CP + hc * 64 + m * 4;
+            const float* ar = att + (q * H + min(m, H - 1)) * NP8 + 8 * g;
+            f32x4 acc[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float4 zz[2][8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) zz[0][e] = *reinterpret_cast<const float4*>(zr + (size_t)min(8 * g + e, N - 1) * CP);
+            auto kstep = [&](int j0, float4 (&cur)[8], float4 (&nxt)[8]) {
+                if (j0 + 32 < N) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        nxt[e] = *reinterpret_cast<const float4*>(zr + (size_t)min(j0 + 32 + 8 * g + e, N - 1) * CP);
+                }
+                const bool live = j0 + 8 * g < NP8;                               // att is zero padded up to NP8 only
+                const float4 a0 = *reinterpret_cast<const float4*>(ar + (live ? j0 : 0));
+                const float4 a1 = *reinterpret_cast<const float4*>(ar + (live ? j0 : 0) + 4);
+                const float xa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                h8 ah, al;
+                hx_split8(xa, live ? sa : 0.0f, ah, al);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float xb[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xb[e] = r == 0 ? cur[e].x : r == 1 ? cur[e].y : r == 2 ? cur[e].z : cur[e].w;
+                    h8 bh, bl;
+                    hx_split8(xb, sp, bh, bl);
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[r], 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[r], 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[r], 0, 0, 0);
+                }
+            };
+            for (int j0 = 0; j0 < N; j0 += 64) {
+                kstep(j0, zz[0], zz[1]);
+                if (j0 + 32 < N) kstep(j0 + 32, zz[1], zz[0]);
+            }
+            float* op = cat + (size_t)row * NCAT + HC + H * PV * 4 + hc * 64 + m * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int hh = 4 * g + r;                                          // D row of register r
+                if (hh < H)
+                    *reinterpret_cast<float4*>(op + hh * CP) =
+                        make_float4(acc[0][r] * inv, acc[1][r] * inv, acc[2][r] * inv, acc[3][r] * inv);
+            }
+        }
+        __syncthreads();                                                           // opt (o_pt sums) is read below
+    } else {
     // o_pair, one query after the other: thread = (channel quad c4, j-group jg of 16); 8 rows in flight
     const int c4 = tid & 31, jg = tid >> 5;
 #pragma unroll 1
@@ -985,6 +1308,7 @@ __global__ __launch_bounds__(512) void k_ipa_attn_q(const float* __restrict__ pr
             for (int u = tid; u < tot; u += 512) op[u] = (red[u] + red[tot + u]) + (red[2 * tot + u] + red[3 * tot + u]);
         }
         __syncthreads();
+    }
     }
     {
         constexpr int np = H * PV;
@@ -1055,13 +1379,13 @@ static bool ipa_is_base(const genie_dims_t& d) {
 static size_t ipa_attn_t1_lds(const genie_dims_t& d, int N) {      // k_ipa_attn_t<12, 16, 4, 8> (single query; long structures)
     return ((size_t)d.n_head_ipa * ((N + 7) & ~7) + 4 * d.n_head_ipa * d.c_p + d.n_head_ipa * d.n_v_point * 3) * sizeof(float);
 }
-static size_t ipa_attn_q_lds(const genie_dims_t& d, int N);
+static size_t ipa_attn_q_lds(const genie_dims_t& d, int N, bool mf = false);
 static bool ipa_use_q(const genie_dims_t& d, int N) { return ipa_attn_q_lds(d, N) <= 160 * 1024; }
 static size_t ipa_attn_t_lds(const genie_dims_t& d, int N) { return ipa_use_q(d, N) ? ipa_attn_q_lds(d, N) : ipa_attn_t1_lds(d, N); }
-static size_t ipa_attn_q_lds(const genie_dims_t& d, int N) {       // k_ipa_attn_q<12, 16, 4, 8, IPA_Q>
+static size_t ipa_attn_q_lds(const genie_dims_t& d, int N, bool mf) {   // k_ipa_attn_q<12, 16, 4, 8, IPA_Q, mf>: no reduction buffer with mf
     const size_t H = d.n_head_ipa;
     return ((size_t)IPA_Q * H * ((N + 7) & ~7) + IPA_Q * H * d.c_hidden_ipa + IPA_Q * H * d.n_qk_point * 3 + 16 +
-            IPA_Q * H * d.n_v_point * 3 + 4 * H * d.c_p) * sizeof(float);
+            IPA_Q * H * d.n_v_point * 3 + (mf ? 0 : 4 * H * d.c_p)) * sizeof(float);
 }
 size_t ipa_attn_lds(const genie_dims_t& d, int N) {
     if (ipa_is_base(d)) return ipa_attn_t_lds(d, N);
@@ -1079,9 +1403,16 @@ void launch_ipa_attn(genie_ctx* h, hipStream_t st, int layer, const float* head_
         return;
     }
     if (ipa_is_base(d)) {
-        hipLaunchKernelGGL((k_ipa_attn_q<12, 16, 4, 8, IPA_Q>), dim3(h->B * ((h->N + IPA_Q - 1) / IPA_Q)), dim3(512),
-                           ipa_attn_t_lds(d, h->N), st, h->proj, ldp, h->kT, h->v, h->qp, h->kpT, h->vp, h->ipa_bias, h->p, h->rots_w,
-                           h->trans_w, h->rmaskf, head_w, h->cat, h->B, h->N, layer, (int)((layer ^ h->hx_launches ^ 1) & 1));
+        const dim3 grid(h->B * ((h->N + IPA_Q - 1) / IPA_Q));
+        const int rev = (int)((layer ^ h->hx_launches ^ 1) & 1);
+        if (h->hx)
+            hipLaunchKernelGGL((k_ipa_attn_q<12, 16, 4, 8, IPA_Q, 1>), grid, dim3(512), ipa_attn_q_lds(d, h->N, true), st, h->proj, ldp,
+                               h->kT, h->v, h->qp, h->kpT, h->vp, h->ipa_bias, h->p, h->rots_w, h->trans_w, h->rmaskf, head_w, h->cat,
+                               h->B, h->N, layer, rev, h->pmax);
+        else
+            hipLaunchKernelGGL((k_ipa_attn_q<12, 16, 4, 8, IPA_Q, 0>), grid, dim3(512), ipa_attn_q_lds(d, h->N), st, h->proj, ldp,
+                               h->kT, h->v, h->qp, h->kpT, h->vp, h->ipa_bias, h->p, h->rots_w, h->trans_w, h->rmaskf, head_w, h->cat,
+                               h->B, h->N, layer, rev, h->pmax);
         return;
     }
     hipLaunchKernelGGL(k_ipa_attn, dim3(h->B * h->N), dim3(256), ipa_attn_lds(d, h->N), st, h->proj, ldp, h->kT, h->v, h->qp,
@@ -1094,6 +1425,27 @@ void launch_bb_update(genie_ctx* h, hipStream_t st, const StructLayerW& w, const
     const int M = h->B * h->N;
     hipLaunchKernelGGL(k_bb_update, dim3((M + 3) / 4), dim3(256), 0, st, h->s, h->d.c_s, w.bb_w, w.bb_b, h->rots_w, h->trans_w,
                        M, trans_in, z_out, 1.0f / h->d.rescale);
+}
+
+static size_t struct_rows_lds() { return (size_t)2 * 32 * SR_LD * 4 + 4 * 32 * GH_ROWB + 2 * 32 * 4; }
+static const HxGemmW* hx_image(const genie_ctx* h, const float* Wp) {
+    for (int i = 0; i < h->n_hxg; ++i)
+        if (h->hxg[i].w == Wp) return &h->hxg[i];
+    return nullptr;
+}
+// LayerNorm -> structure transition -> LayerNorm -> BackboneUpdate on h->s1, one launch; false = this configuration keeps the
+// separate launches (f32 arithmetic, c_s != 384)
+bool launch_struct_rows(genie_ctx* h, hipStream_t st, const StructLayerW& S, const float* trans_in, float* z_out) {
+    if (!h->hx || h->d.c_s != 384 || getenv("GENIE_NO_STRUCT_FUSE")) return false;
+    const HxGemmW *w1 = hx_image(h, S.t1_w), *w2 = hx_image(h, S.t2_w), *w3 = hx_image(h, S.t3_w);
+    if (!w1 || !w2 || !w3) return false;
+    ProfScope ps(h, st, KC_STRUCT_ROWS);
+    const int M = h->B * h->N;
+    const int nrb = (M + 31) / 32;                 // row work-groups; + 64 L2 prefetchers (8 per XCD) on CUs the rows leave idle
+    hipLaunchKernelGGL((k_struct_rows_hx<12>), dim3(nrb + 64), dim3(768), struct_rows_lds(), st, h->s1, S.ln_ipa_g, S.ln_ipa_b,
+                       w1->img, w1->inv_s, S.t1_b, w2->img, w2->inv_s, S.t2_b, w3->img, w3->inv_s, S.t3_b, S.ln_tr_g, S.ln_tr_b,
+                       S.bb_w, S.bb_b, h->s, h->rots_w, h->trans_w, M, trans_in, z_out, 1.0f / h->d.rescale, nrb);
+    return true;
 }
 
 void launch_frenet(genie_ctx* h, hipStream_t st, int mode, int step, float scale, float* trans, float* rots, const float* z,
@@ -1123,11 +1475,15 @@ void launch_scale_copy(genie_ctx* h, hipStream_t st, const float* in, float* out
 }
 
 void single_kernels_init(const genie_dims_t& d, int n_max) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_struct_rows_hx<12>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)struct_rows_lds());
     if (ipa_is_base(d)) {
-        if (ipa_use_q(d, n_max))
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn_q<12, 16, 4, 8, IPA_Q>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)ipa_attn_q_lds(d, n_max));
-        else
+        if (ipa_use_q(d, n_max)) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn_q<12, 16, 4, 8, IPA_Q, 0>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipa_attn_q_lds(d, n_max));
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn_q<12, 16, 4, 8, IPA_Q, 1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipa_attn_q_lds(d, n_max, true));
+        } else
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn_t<12, 16, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)ipa_attn_t1_lds(d, n_max));
     } else
