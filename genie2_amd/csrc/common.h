@@ -226,6 +226,7 @@ struct genie_ctx {
     // workspace (one allocation, carved)
     void* ws; size_t ws_bytes;
     float *p, *acm, *bcm, *xcm, *pstatic, *ipa_bias;
+    float *spart;                 // [3][B N][c_s] split-K slices of the IPA output projection
     unsigned *pmax;               // bits of max |p| over the pair tensor the IPA layers read (k_ipa_bias -> k_ipa_attn_q)
     float *xsingle, *s0, *s, *s1, *s2, *h1, *h2, *pij, *proj, *cat;
     float *kT, *v, *qp, *kpT, *vp;
@@ -255,7 +256,7 @@ void launch_pair_transition(genie_ctx* h, hipStream_t st, const PairLayerW& w);
 void launch_ipa_bias(genie_ctx* h, hipStream_t st);
 void launch_ipa_prep(genie_ctx* h, hipStream_t st);
 void launch_ipa_attn(genie_ctx* h, hipStream_t st, int layer, const float* head_w);
-bool launch_struct_rows(genie_ctx* h, hipStream_t st, const StructLayerW& S, const float* trans_in, float* z_out);
+bool launch_struct_tail(genie_ctx* h, hipStream_t st, const StructLayerW& S, const float* trans_in, float* z_out);
 void launch_bb_update(genie_ctx* h, hipStream_t st, const StructLayerW& w, const float* trans_in,
                       float* z_out);
 void launch_frenet(genie_ctx* h, hipStream_t st, int mode, int step, float scale, float* trans,

@@ -508,7 +508,7 @@ int genie_prepare_features(genie_handle_t h, genie_stream_t stream, int B, int N
     want(&h->kT, M * H * C * 4); want(&h->v, M * H * C * 4); want(&h->qp, M * H * Pq * 3 * 4);
     want(&h->kpT, M * H * Pq * 3 * 4); want(&h->vp, M * H * Pv * 3 * 4);
     want(&h->rots_w, M * 9 * 4); want(&h->trans_w, M * 3 * 4); want(&h->loop_z, M * 3 * 4);
-    want(&h->tsteps, (size_t)B * 4); want(&h->rmaskf, M * 4); want(&h->pmax, 4);
+    want(&h->tsteps, (size_t)B * 4); want(&h->rmaskf, M * 4); want(&h->pmax, 4); want(&h->spart, 3 * M * cs * 4);
     want(&h->f_aatype, M * 20 * 4); want(&h->f_rmask, M * 4); want(&h->f_ridx, M * 4); want(&h->f_cidx, M * 4);
     want(&h->f_pos, M * 3 * 4); want(&h->f_fsm, M); want(&h->f_fstm, P); want(&h->f_ifm, M);
     size_t total = 0;
@@ -587,8 +587,8 @@ static int denoise_internal(genie_ctx* h, hipStream_t st, const float* trans, co
             launch_gemm_rows(h, st, h->s, cs, M, cs, S.proj_w, nproj, S.proj_b, nullptr, 0, nullptr, 0, h->proj, nproj);
             launch_ipa_prep(h, st);
             launch_ipa_attn(h, st, l, S.head_w);
+            if (launch_struct_tail(h, st, S, last ? trans : nullptr, last ? z_out : nullptr)) continue;
             launch_gemm_rows(h, st, h->cat, ncat, M, ncat, S.out_w, cs, S.out_b, h->s, cs, nullptr, 0, h->s1, cs);
-            if (launch_struct_rows(h, st, S, last ? trans : nullptr, last ? z_out : nullptr)) continue;
             launch_layernorm_rows(h, st, h->s1, h->s2, M, cs, S.ln_ipa_g, S.ln_ipa_b);
             launch_gemm_rows(h, st, h->s2, cs, M, cs, S.t1_w, cs, S.t1_b, nullptr, 0, nullptr, 1, h->h1, cs);
             launch_gemm_rows(h, st, h->h1, cs, M, cs, S.t2_w, cs, S.t2_b, nullptr, 0, nullptr, 1, h->h2, cs);

@@ -144,17 +144,25 @@ __global__ __launch_bounds__(256) void k_gemm_rows(const float* __restrict__ A, 
 __global__ __launch_bounds__(256) void k_gemm_rows_hx(const float* __restrict__ A, int lda, int M, int K,
                                                       const unsigned char* __restrict__ Wx, int Nout, float inv_sw,
                                                       const float* __restrict__ bias, const float* __restrict__ res, int ldr,
-                                                      const float* __restrict__ rowmask, int relu, float* __restrict__ out, int ldo) {
+                                                      const float* __restrict__ rowmask, int relu, float* __restrict__ out, int ldo,
+                                                      size_t zstride) {
     __shared__ __attribute__((aligned(16))) unsigned char sa[2][2][32 * GH_ROWB];   // [buffer][hi | lo]
     __shared__ __attribute__((aligned(16))) float sinv[2][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = blockIdx.x * 32;
     const int nb = min((int)(blockIdx.y * 4 + wave), (Nout + 31) / 32 - 1);   // idle waves shadow the last block
     const bool active = (int)(blockIdx.y * 4 + wave) * 32 < Nout;
+    // split-K (gridDim.z > 1; the 33 chunks of the IPA output projection): slice z owns chunks [c0, c1) and writes its raw partial
+    // product to out + z * zstride (callers pass no bias / residual / mask and sum the slices where they read them)
+    const int KCt = (K + 15) >> 4, nkct = (K + 63) >> 6;
+    const int c0 = (int)blockIdx.z * nkct / (int)gridDim.z, c1 = ((int)blockIdx.z + 1) * nkct / (int)gridDim.z;
+    const float* wbase = reinterpret_cast<const float*>(Wx + ((size_t)nb * KCt + (size_t)c0 * 4) * 2048) + lane * 4;   // unit u: + u*512 floats; lo: + 256
+    A += c0 * 64;
+    K = min(K, c1 * 64) - c0 * 64;
+    out += (size_t)blockIdx.z * zstride;
     const int KC = (K + 15) >> 4;                // 16-wide weight units
     const int nkc = (K + 63) >> 6;               // 64-wide activation chunks
     const int lr = tid >> 4, c4 = tid & 15;      // 16 rows x 16 float4 per pass, 2 passes
-    const float* wbase = reinterpret_cast<const float*>(Wx + (size_t)nb * KC * 2048) + lane * 4;   // unit u: + u*512 floats; lo: + 256
 
     v4f wh[GH_PD], wl[GH_PD];
 #pragma unroll
@@ -732,26 +740,30 @@ __global__ __launch_bounds__(256) void k_bb_update(const float* __restrict__ s, 
 // out of the LDS tile instead of HBM, and writes its result tile in place once the last chunk has been split.
 // ---------------------------------------------------------------------------
 #define SR_PD 4
+#define SR_KSPLIT 3          // split-K slices of the IPA output projection summed by the loader
 #define SR_LD 388            // floats per row of an activation tile (384 + 4: the two half-waves of a D store hit disjoint banks)
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_struct_rows_hx(
     // (parameters of later stages are deliberately not __restrict__: hipcc would hoist their loads -- 60 registers of LayerNorm
     //  and BackboneUpdate weights -- to the top of the kernel, across the barriers, and spill the GEMM loop)
-    const float* __restrict__ x, const float* g1, const float* be1, const unsigned char* __restrict__ W1, float i1, const float* b1,
+    const float* __restrict__ x, int nsplit, size_t zstride, const float* __restrict__ xbias, const float* xres,
+    const float* g1, const float* be1, const unsigned char* __restrict__ W1, float i1, const float* b1,
     const unsigned char* __restrict__ W2, float i2, const float* b2, const unsigned char* __restrict__ W3, float i3, const float* b3,
     const float* g2, const float* be2, const float* bbw, const float* bbb, float* s_out, float* rots, float* trans, int M,
-    const float* trans_in, float* z_out, float inv_rescale, int nrb) {
+    const float* trans_in, float* z_out, float inv_rescale, int nrb, unsigned long long* ts) {
     constexpr int C = NW * 32, NT = NW * 64, KC = C / 16, NKC = C / 64;
     static_assert(C % 64 == 0 && NT >= 512 && NT <= 1024 && C + 4 <= SR_LD, "shape");
     extern __shared__ __attribute__((aligned(16))) float srm[];
     float* T0 = srm;
     float* T1 = T0 + 32 * SR_LD;
-    unsigned char* sa = reinterpret_cast<unsigned char*>(T1 + 32 * SR_LD);       // [buffer][hi | lo][32 * GH_ROWB]
-    float* sinv = reinterpret_cast<float*>(sa + 4 * 32 * GH_ROWB);               // [buffer][32]
+    unsigned char* sa = reinterpret_cast<unsigned char*>(T1 + 32 * SR_LD);       // [chunk][hi | lo][32 * GH_ROWB]
+    float* sinv = reinterpret_cast<float*>(sa + NKC * 2 * 32 * GH_ROWB);         // [chunk][32]
+    float* frm = sinv + NKC * 32;                                                  // [32][12] frames of the rows (R | t)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = blockIdx.x * 32;
-    const int lr = tid >> 4, c4 = tid & 15;                                      // splitter: threads 0..511 = 32 rows x 16 float4
     const bool splitter = tid < 512;
+    int ts_n = 0;                                  // developer aid (GENIE_SR_TS=1): s_memtime at the phase boundaries of work-group 0
+    auto stamp = [&]() { if (ts && blockIdx.x == 0 && tid == 0) ts[ts_n++] = __builtin_amdgcn_s_memtime(); };
 
     if ((int)blockIdx.x >= nrb) {
         // The layer's three weight images (1.7 MB) were last used a whole denoiser step ago: they come from HBM, and a row
@@ -785,57 +797,101 @@ __global__ __launch_bounds__(NW * 64) void k_struct_rows_hx(
 #pragma unroll
         for (int u = 0; u < SR_PD; ++u) unit_issue(wb, wh[u], wl[u], u);
     };
+    stamp();
     ring_fill(W1);
 
-    for (int u = tid; u < 32 * (C / 4); u += NT) {
-        const int r = u / (C / 4), q = u - r * (C / 4);
-        *reinterpret_cast<float4*>(T0 + r * SR_LD + q * 4) =
-            *reinterpret_cast<const float4*>(x + (size_t)min(r0 + r, M - 1) * C + q * 4);
+    // s1 = sum of the output projection's split-K slices + its bias + the residual s (nsplit = 0: x is s1 itself); every load
+    // of a thread's four float4 is issued before the first is used
+    {
+        constexpr int NI = 32 * (C / 4) / NT;
+        static_assert(32 * (C / 4) % NT == 0 && SR_KSPLIT == 3, "loader shape");
+        float4 v[NI], w1[NI], w2[NI], rq[NI], bq[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int u = tid + i * NT, r = u / (C / 4), q = u - r * (C / 4);
+            const size_t o = (size_t)min(r0 + r, M - 1) * C + q * 4;
+            v[i] = *reinterpret_cast<const float4*>(x + o);
+            if (nsplit) {
+                w1[i] = *reinterpret_cast<const float4*>(x + zstride + o);
+                w2[i] = *reinterpret_cast<const float4*>(x + 2 * zstride + o);
+                rq[i] = *reinterpret_cast<const float4*>(xres + o);
+                bq[i] = *reinterpret_cast<const float4*>(xbias + q * 4);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int u = tid + i * NT, r = u / (C / 4), q = u - r * (C / 4);
+            float4 t = v[i];
+            if (nsplit) {
+                t.x = (((t.x + w1[i].x) + w2[i].x) + bq[i].x) + rq[i].x; t.y = (((t.y + w1[i].y) + w2[i].y) + bq[i].y) + rq[i].y;
+                t.z = (((t.z + w1[i].z) + w2[i].z) + bq[i].z) + rq[i].z; t.w = (((t.w + w1[i].w) + w2[i].w) + bq[i].w) + rq[i].w;
+            }
+            *reinterpret_cast<float4*>(T0 + r * SR_LD + q * 4) = t;
+        }
+    }
+    // frames of the tile's rows (R 9 floats, t 3) for the composition at the end: fetched now, used 40 us later
+    if (tid < 32 * 12) {
+        const int r = tid / 12, k = tid - r * 12, row = min(r0 + r, M - 1);
+        frm[tid] = k < 9 ? rots[(size_t)row * 9 + k] : trans[(size_t)row * 3 + (k - 9)];
     }
     __syncthreads();
 
-    // nn.LayerNorm of the tile's rows in place (k_layernorm_rows' arithmetic: one wave per row, same lane -> column map)
+    // 16 lanes per row, four rows per wave: the 32 rows of the tile in one round on waves 0..7; reductions are four DPP steps
+    auto dpp_add = [](float m, auto ctrl_tag) {
+        constexpr int CTRL = decltype(ctrl_tag)::value;
+        return m + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), CTRL, 0xf, 0xf, false));
+    };
+    auto row16_sum = [&](float m) {
+        m = dpp_add(m, std::integral_constant<int, 0xB1>{});       // quad_perm [1,0,3,2]
+        m = dpp_add(m, std::integral_constant<int, 0x4E>{});       // quad_perm [2,3,0,1]
+        m = dpp_add(m, std::integral_constant<int, 0x124>{});      // row_ror:4
+        m = dpp_add(m, std::integral_constant<int, 0x128>{});      // row_ror:8
+        return m;
+    };
+    const int l16 = tid & 15, rrow = tid >> 4;                    // row of this lane group (valid for tid < 512)
+    // nn.LayerNorm of the tile's rows in place (two-pass, as k_layernorm_rows; a lane owns columns 4 l16 + 64 q .. + 3)
     auto layernorm = [&](float* T, const float* g, const float* bta, float* gout) {
-        for (int r = wave; r < 32; r += NW) {
-            float v[C / 64];
+        if (splitter) {
+            float4 v[C / 64];
             float sum = 0.f;
 #pragma unroll
-            for (int q = 0; q < C / 64; ++q) { v[q] = T[r * SR_LD + lane + 64 * q]; sum += v[q]; }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-            const float mean = sum / (float)C;
+            for (int q = 0; q < C / 64; ++q) {
+                v[q] = *reinterpret_cast<const float4*>(T + rrow * SR_LD + 64 * q + 4 * l16);
+                sum += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+            }
+            const float mean = row16_sum(sum) / (float)C;
             float ss = 0.f;
 #pragma unroll
-            for (int q = 0; q < C / 64; ++q) { const float d = v[q] - mean; ss += d * d; }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-            const float rstd = 1.0f / sqrtf(ss / (float)C + GENIE_LN_EPS);
+            for (int q = 0; q < C / 64; ++q) {
+                const float dx = v[q].x - mean, dy = v[q].y - mean, dz = v[q].z - mean, dw = v[q].w - mean;
+                ss += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+            const float rstd = 1.0f / sqrtf(row16_sum(ss) / (float)C + GENIE_LN_EPS);
 #pragma unroll
             for (int q = 0; q < C / 64; ++q) {
-                const int c = lane + 64 * q;
-                const float y = (v[q] - mean) * rstd * g[c] + bta[c];
-                T[r * SR_LD + c] = y;
-                if (gout && r0 + r < M) gout[(size_t)(r0 + r) * C + c] = y;
+                const int c = 64 * q + 4 * l16;
+                const float4 gq = *reinterpret_cast<const float4*>(g + c), bq = *reinterpret_cast<const float4*>(bta + c);
+                float4 y;
+                y.x = (v[q].x - mean) * rstd * gq.x + bq.x; y.y = (v[q].y - mean) * rstd * gq.y + bq.y;
+                y.z = (v[q].z - mean) * rstd * gq.z + bq.z; y.w = (v[q].w - mean) * rstd * gq.w + bq.w;
+                *reinterpret_cast<float4*>(T + rrow * SR_LD + c) = y;
+                if (gout && r0 + rrow < M) *reinterpret_cast<float4*>(gout + (size_t)(r0 + rrow) * C + c) = y;
             }
         }
         __syncthreads();
     };
 
-    // one LDS address per thread, everything else as instruction offsets (registers are what this kernel is short of)
-    unsigned char* const sdst = sa + lr * GH_ROWB + c4 * 8;
-    float* const sidst = sinv + lr;
-    const int aoff = lr * SR_LD + c4 * 4;
     auto dpp_max = [](float m, auto ctrl_tag) {
         constexpr int CTRL = decltype(ctrl_tag)::value;
         return fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), CTRL, 0xf, 0xf, false)));
     };
-    auto split_store = [&](float4 v, auto buf_tag) {
-        constexpr int BUF = decltype(buf_tag)::value;
+    // block-floating-point split of one float4 of A (16 consecutive lanes = one row's 64-wide K chunk) into the operand planes
+    auto split_store = [&](float4 v, int row, int kc) {
         float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
         m = dpp_max(m, std::integral_constant<int, 0xB1>{});       // quad_perm [1,0,3,2]
         m = dpp_max(m, std::integral_constant<int, 0x4E>{});       // quad_perm [2,3,0,1]
         m = dpp_max(m, std::integral_constant<int, 0x124>{});      // row_ror:4
-        m = dpp_max(m, std::integral_constant<int, 0x128>{});      // row_ror:8  -> largest |a| of the row's 64-wide chunk (16 lanes)
+        m = dpp_max(m, std::integral_constant<int, 0x128>{});      // row_ror:8  -> largest |a| of the row's chunk
         const int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 255u);
         const bool tiny = e < 16;
         const float sc = tiny ? 1.0f : __builtin_bit_cast(float, (unsigned)(268 - e) << 23);
@@ -843,23 +899,28 @@ __global__ __launch_bounds__(NW * 64) void k_struct_rows_hx(
         unsigned h01, l01, h23, l23;
         hx_split2(v.x, v.y, sc, h01, l01);
         hx_split2(v.z, v.w, sc, h23, l23);
-        *reinterpret_cast<uint2*>(sdst + (BUF * 2 + 0) * 32 * GH_ROWB) = make_uint2(h01, h23);
-        *reinterpret_cast<uint2*>(sdst + (BUF * 2 + 1) * 32 * GH_ROWB) = make_uint2(l01, l23);
-        if (c4 == 0) sidst[BUF * 32] = isc;
+        unsigned char* d = sa + kc * (2 * 32 * GH_ROWB) + row * GH_ROWB + l16 * 8;
+        *reinterpret_cast<uint2*>(d) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(d + 32 * GH_ROWB) = make_uint2(l01, l23);
+        if (l16 == 0) sinv[kc * 32 + row] = isc;
     };
 
-    // out = act(A W^T inv_sw + bias) (+ res), tiles in LDS; `out` may alias A
+    // out = act(A W^T inv_sw + bias) (+ res), tiles in LDS; `out` may alias A.  All NKC chunks of A are split up front (one
+    // barrier), then every wave runs its 72 MFMAs against the weight ring without meeting the others again.
     auto linear = [&](const float* A, const unsigned char* __restrict__ Wx, const unsigned char* Wnext, float inv_sw,
                       const float* bias, bool relu, const float* res, float* out) {
         const unsigned char* wb = Wx + (size_t)wsel * KC * 2048;
-        if (splitter) split_store(*reinterpret_cast<const float4*>(A + aoff), std::integral_constant<int, 0>{});
+#pragma unroll
+        for (int i = 0; i < 32 * (C / 4) / NT; ++i) {
+            const int u = tid + i * NT, rc = u >> 4, row = rc / NKC, kc = rc - row * NKC;      // u = ((row NKC + kc) 16 + l16)
+            split_store(*reinterpret_cast<const float4*>(A + row * SR_LD + kc * 64 + l16 * 4), row, kc);
+        }
         __syncthreads();
         f32x16 acc = zero16();
         const int foff = (lane & 31) * GH_ROWB + (lane >> 5) * 16;
-        auto chunk = [&](int kc, auto par_tag) {
-            constexpr int PAR = decltype(par_tag)::value;
-            const int kcn = min(kc + 1, NKC - 1);
-            const unsigned char* cur = sa + PAR * 2 * 32 * GH_ROWB + foff;
+#pragma unroll 1
+        for (int kc = 0; kc < NKC; ++kc) {
+            const unsigned char* cur = sa + kc * (2 * 32 * GH_ROWB) + foff;
             f32x16 part = zero16();
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -871,27 +932,18 @@ __global__ __launch_bounds__(NW * 64) void k_struct_rows_hx(
                 __builtin_amdgcn_sched_barrier(0);
                 unit_issue(wb, wh[q], wl[q], kc * 4 + q + SR_PD);
             }
-            {
-                const float* si = sinv + PAR * 32 + 4 * (lane >> 5);
+            const float* si = sinv + kc * 32 + 4 * (lane >> 5);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 iv = *reinterpret_cast<const float4*>(si + 8 * g);
-                    acc[4 * g] = fmaf(part[4 * g], iv.x, acc[4 * g]); acc[4 * g + 1] = fmaf(part[4 * g + 1], iv.y, acc[4 * g + 1]);
-                    acc[4 * g + 2] = fmaf(part[4 * g + 2], iv.z, acc[4 * g + 2]); acc[4 * g + 3] = fmaf(part[4 * g + 3], iv.w, acc[4 * g + 3]);
-                }
+            for (int g = 0; g < 4; ++g) {
+                const float4 iv = *reinterpret_cast<const float4*>(si + 8 * g);
+                acc[4 * g] = fmaf(part[4 * g], iv.x, acc[4 * g]); acc[4 * g + 1] = fmaf(part[4 * g + 1], iv.y, acc[4 * g + 1]);
+                acc[4 * g + 2] = fmaf(part[4 * g + 2], iv.z, acc[4 * g + 2]); acc[4 * g + 3] = fmaf(part[4 * g + 3], iv.w, acc[4 * g + 3]);
             }
-            if (splitter) split_store(*reinterpret_cast<const float4*>(A + kcn * 64 + aoff), std::integral_constant<int, PAR ^ 1>{});
-            __syncthreads();
-        };
-#pragma unroll 1
-        for (int kc = 0; kc < NKC; kc += 2) {
-            chunk(kc, std::integral_constant<int, 0>{});
-            if (kc + 1 < NKC) chunk(kc + 1, std::integral_constant<int, 1>{});
         }
 #pragma unroll
         for (int u = 0; u < SR_PD; ++u) wf_wait<0>(wh[u], wl[u]);
         if (Wnext) ring_fill(Wnext);
-        // every split of A is done (last barrier above): the result may overwrite it
+        // A was consumed by the split before the barrier above: the result may overwrite it
         const int col = wave * 32 + (lane & 31);
         const float bc = bias[col];
 #pragma unroll
@@ -905,29 +957,38 @@ __global__ __launch_bounds__(NW * 64) void k_struct_rows_hx(
         __syncthreads();
     };
 
+    stamp();
     layernorm(T0, g1, be1, nullptr);                      // T0 = s2
+    stamp();
     linear(T0, W1, W2, i1, b1, true, nullptr, T1);
+    stamp();
     linear(T1, W2, W3, i2, b2, true, nullptr, T1);
+    stamp();
     linear(T1, W3, nullptr, i3, b3, false, T0, T1);
+    stamp();
+    for (int u = tid; u < 6 * C / 4; u += NT)             // BackboneUpdate weights -> T0 (visible after LayerNorm's barrier)
+        reinterpret_cast<float4*>(T0)[u] = reinterpret_cast<const float4*>(bbw)[u];
     layernorm(T1, g2, be2, s_out);                        // T1 = s
+    stamp();
 
-    // BackboneUpdate + frame composition (k_bb_update's arithmetic), one wave per row
-    for (int r = wave; r < 32; r += NW) {
-        const int row = r0 + r;
-        if (row >= M) continue;
+    // BackboneUpdate + frame composition (k_bb_update's arithmetic), 16 lanes per row; the update weights (6 x C) sit in T0,
+    // whose last reader was the third Linear
+    if (splitter) {
         float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int c = lane; c < C; c += 64) {
-            const float xv = T1[r * SR_LD + c];
 #pragma unroll
-            for (int o = 0; o < 6; ++o) acc[o] += xv * bbw[o * C + c];
+        for (int q = 0; q < C / 64; ++q) {
+            const int c = 64 * q + 4 * l16;
+            const float4 xv = *reinterpret_cast<const float4*>(T1 + rrow * SR_LD + c);
+#pragma unroll
+            for (int o = 0; o < 6; ++o) {
+                const float4 wv = *reinterpret_cast<const float4*>(T0 + o * C + c);
+                acc[o] += (xv.x * wv.x + xv.y * wv.y) + (xv.z * wv.z + xv.w * wv.w);
+            }
         }
 #pragma unroll
-        for (int o = 0; o < 6; ++o) {
-#pragma unroll
-            for (int sft = 32; sft > 0; sft >>= 1) acc[o] += __shfl_xor(acc[o], sft);
-            acc[o] += bbb[o];
-        }
-        if (lane == 0) {
+        for (int o = 0; o < 6; ++o) acc[o] = row16_sum(acc[o]) + bbb[o];
+        const int row = r0 + rrow;
+        if (l16 == 0 && row < M) {
             const float qb = acc[0], qc = acc[1], qd = acc[2];
             const float den = sqrtf(((qb * qb + qc * qc) + qd * qd) + 1.0f);
             const float a = 1.0f / den, bq = qb / den, c = qc / den, d = qd / den;
@@ -939,14 +1000,14 @@ __global__ __launch_bounds__(NW * 64) void k_struct_rows_hx(
             float* t = trans + (size_t)row * 3;
             float Rn[9], rr[9];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) rr[k] = R[k];
+            for (int k = 0; k < 9; ++k) rr[k] = frm[rrow * 12 + k];
 #pragma unroll
             for (int xx = 0; xx < 3; ++xx)
 #pragma unroll
                 for (int y = 0; y < 3; ++y) Rn[xx * 3 + y] = rr[xx * 3 + 0] * U[0 * 3 + y] + rr[xx * 3 + 1] * U[1 * 3 + y] + rr[xx * 3 + 2] * U[2 * 3 + y];
-            const float tx = rr[0] * acc[3] + rr[1] * acc[4] + rr[2] * acc[5] + t[0];
-            const float ty = rr[3] * acc[3] + rr[4] * acc[4] + rr[5] * acc[5] + t[1];
-            const float tz = rr[6] * acc[3] + rr[7] * acc[4] + rr[8] * acc[5] + t[2];
+            const float tx = rr[0] * acc[3] + rr[1] * acc[4] + rr[2] * acc[5] + frm[rrow * 12 + 9];
+            const float ty = rr[3] * acc[3] + rr[4] * acc[4] + rr[5] * acc[5] + frm[rrow * 12 + 10];
+            const float tz = rr[6] * acc[3] + rr[7] * acc[4] + rr[8] * acc[5] + frm[rrow * 12 + 11];
 #pragma unroll
             for (int k = 0; k < 9; ++k) R[k] = Rn[k];
             t[0] = tx; t[1] = ty; t[2] = tz;
@@ -957,6 +1018,7 @@ __global__ __launch_bounds__(NW * 64) void k_struct_rows_hx(
             }
         }
     }
+    stamp();
 }
 
 // ---------------------------------------------------------------------------
@@ -1351,7 +1413,7 @@ void launch_gemm_rows(genie_ctx* h, hipStream_t st, const float* A, int lda, int
         for (int i = 0; i < h->n_hxg; ++i)
             if (h->hxg[i].w == Wp) {
                 hipLaunchKernelGGL(k_gemm_rows_hx, grid, dim3(256), 0, st, A, lda, M, K, h->hxg[i].img, Nout, h->hxg[i].inv_s, bias, res,
-                                   ldr, rowmask, relu, out, ldo);
+                                   ldr, rowmask, relu, out, ldo, (size_t)0);
                 return;
             }
     }
@@ -1427,24 +1489,40 @@ void launch_bb_update(genie_ctx* h, hipStream_t st, const StructLayerW& w, const
                        M, trans_in, z_out, 1.0f / h->d.rescale);
 }
 
-static size_t struct_rows_lds() { return (size_t)2 * 32 * SR_LD * 4 + 4 * 32 * GH_ROWB + 2 * 32 * 4; }
+static size_t struct_rows_lds() { return (size_t)2 * 32 * SR_LD * 4 + 6 * (2 * 32 * GH_ROWB + 32 * 4) + 32 * 12 * 4; }   // NKC = 6
 static const HxGemmW* hx_image(const genie_ctx* h, const float* Wp) {
     for (int i = 0; i < h->n_hxg; ++i)
         if (h->hxg[i].w == Wp) return &h->hxg[i];
     return nullptr;
 }
-// LayerNorm -> structure transition -> LayerNorm -> BackboneUpdate on h->s1, one launch; false = this configuration keeps the
-// separate launches (f32 arithmetic, c_s != 384)
-bool launch_struct_rows(genie_ctx* h, hipStream_t st, const StructLayerW& S, const float* trans_in, float* z_out) {
+// IPA output projection (split-K, three slices) and the fused tail (their sum + bias + residual -> LayerNorm -> structure
+// transition -> LayerNorm -> BackboneUpdate), two launches; false = this configuration keeps the separate launches (f32
+// arithmetic, c_s != 384)
+bool launch_struct_tail(genie_ctx* h, hipStream_t st, const StructLayerW& S, const float* trans_in, float* z_out) {
     if (!h->hx || h->d.c_s != 384 || getenv("GENIE_NO_STRUCT_FUSE")) return false;
-    const HxGemmW *w1 = hx_image(h, S.t1_w), *w2 = hx_image(h, S.t2_w), *w3 = hx_image(h, S.t3_w);
-    if (!w1 || !w2 || !w3) return false;
+    const HxGemmW *w0 = hx_image(h, S.out_w), *w1 = hx_image(h, S.t1_w), *w2 = hx_image(h, S.t2_w), *w3 = hx_image(h, S.t3_w);
+    if (!w0 || !w1 || !w2 || !w3) return false;
+    const int M = h->B * h->N, cs = h->d.c_s, ncat = h->d.n_head_ipa * (h->d.c_p + h->d.c_hidden_ipa + 4 * h->d.n_v_point);
+    const size_t zs = (size_t)M * cs;
+    {
+        ProfScope ps(h, st, KC_GEMM_ROWS);
+        hipLaunchKernelGGL(k_gemm_rows_hx, dim3((M + 31) / 32, (cs + 127) / 128, SR_KSPLIT), dim3(256), 0, st, h->cat, ncat, M, ncat,
+                           w0->img, cs, w0->inv_s, nullptr, nullptr, 0, nullptr, 0, h->spart, cs, zs);
+    }
     ProfScope ps(h, st, KC_STRUCT_ROWS);
-    const int M = h->B * h->N;
+    static unsigned long long* ts = nullptr;
+    if (!ts && getenv("GENIE_SR_TS")) hipMalloc((void**)&ts, 64 * sizeof(unsigned long long));
     const int nrb = (M + 31) / 32;                 // row work-groups; + 64 L2 prefetchers (8 per XCD) on CUs the rows leave idle
-    hipLaunchKernelGGL((k_struct_rows_hx<12>), dim3(nrb + 64), dim3(768), struct_rows_lds(), st, h->s1, S.ln_ipa_g, S.ln_ipa_b,
-                       w1->img, w1->inv_s, S.t1_b, w2->img, w2->inv_s, S.t2_b, w3->img, w3->inv_s, S.t3_b, S.ln_tr_g, S.ln_tr_b,
-                       S.bb_w, S.bb_b, h->s, h->rots_w, h->trans_w, M, trans_in, z_out, 1.0f / h->d.rescale, nrb);
+    hipLaunchKernelGGL((k_struct_rows_hx<12>), dim3(nrb + 64), dim3(768), struct_rows_lds(), st, h->spart, SR_KSPLIT, zs, S.out_b, h->s,
+                       S.ln_ipa_g, S.ln_ipa_b, w1->img, w1->inv_s, S.t1_b, w2->img, w2->inv_s, S.t2_b, w3->img, w3->inv_s, S.t3_b,
+                       S.ln_tr_g, S.ln_tr_b, S.bb_w, S.bb_b, h->s, h->rots_w, h->trans_w, M, trans_in, z_out, 1.0f / h->d.rescale, nrb, ts);
+    if (ts) {
+        unsigned long long v[8] = {0};
+        hipStreamSynchronize(st);
+        hipMemcpy(v, ts, sizeof(v), hipMemcpyDeviceToHost);
+        fprintf(stderr, "struct_rows wg0 (100 MHz ticks): load %llu ln %llu lin1 %llu lin2 %llu lin3 %llu ln %llu bb %llu total %llu\n", v[1] - v[0],
+                v[2] - v[1], v[3] - v[2], v[4] - v[3], v[5] - v[4], v[6] - v[5], v[7] - v[6], v[7] - v[0]);
+    }
     return true;
 }
 

@@ -345,3 +345,26 @@ def test_sampler_api_end_to_end(tmp_path, base_weights):
     out = model.model(T(rots, x), torch.tensor([20], dtype=torch.int32), feats, outputs=('z', 's', 'p', 'states', 'ts'))
     assert out['z'].shape == (1, 30, 3) and out['p'].shape == (1, 30, 30, 128) and out['states'].shape == (2, 1, 30, 384)
     assert out['ts'].rots.shape == (1, 30, 3, 3)
+
+
+def test_fused_structure_tail_matches_separate_launches(base_engine, monkeypatch):
+    """k_struct_rows_hx (split-K output projection summed on load, LayerNorm, transition, LayerNorm, BackboneUpdate in
+    one launch) against the seven separate launches it replaces (GENIE_NO_STRUCT_FUSE): same arithmetic up to summation
+    order.  Ragged batch whose row count is not a multiple of the 32-row tile."""
+    f = O.empty_features([45, 23, 38])
+    B, N = f['residue_mask'].shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, N, 3, generator=g) * 4
+    base_engine.set_math('hx')
+    base_engine.bind_features(f)
+    r = base_engine.frenet(x)
+    ts = torch.tensor([900, 17, 333], dtype=torch.int32)
+    monkeypatch.delenv('GENIE_NO_STRUCT_FUSE', raising=False)
+    zf = base_engine.denoise(x, r, ts, None, taps=('s_final',))
+    monkeypatch.setenv('GENIE_NO_STRUCT_FUSE', '1')
+    zs = base_engine.denoise(x, r, ts, None, taps=('s_final',))
+    monkeypatch.delenv('GENIE_NO_STRUCT_FUSE', raising=False)
+    for k in ('z', 's_final'):
+        a, b = zf[k].cpu(), zs[k].cpu()
+        assert torch.isfinite(a).all()
+        assert mdiff(a, b) <= 4e-6 * max(1.0, float(b.abs().max())), k
