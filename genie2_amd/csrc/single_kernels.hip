@@ -1138,17 +1138,20 @@ __global__ void k_scale_copy(const float* __restrict__ in, float* __restrict__ o
 // loads e = 0..7 is exactly the B fragment of the block holding channels {4m + r}, so the stream needs no LDS and no
 // shuffles, and the accumulators of the four blocks form the float4 a lane stores.  No cross-wave reduction, no barrier.
 template <int H, int C, int PQ, int PV, int Q, int MF>
-__global__ __launch_bounds__(512) void k_ipa_attn_q(const float* __restrict__ proj, int ldp, const float* __restrict__ kT,
+__global__ __launch_bounds__(MF ? 128 * Q : 512) void k_ipa_attn_q(const float* __restrict__ proj, int ldp, const float* __restrict__ kT,
                                                     const float* __restrict__ v, const float* __restrict__ qp,
                                                     const float* __restrict__ kpT, const float* __restrict__ vp,
                                                     const float* __restrict__ bias, const float* __restrict__ z,
                                                     const float* __restrict__ rots, const float* __restrict__ trans,
                                                     const float* __restrict__ rmask, const float* __restrict__ head_w,
                                                     float* __restrict__ cat, int B, int N, int layer, int rev,
-                                                    const unsigned* __restrict__ pmax) {
-    constexpr int CP = 128, HC = H * C, NQP = H * PQ * 3, NPT = H * PV * 3, NCAT = HC + H * PV * 4 + H * CP, HH = H / 2;
-    static_assert(H % 2 == 0 && C % 4 == 0 && HC + NPT <= 512, "shape");
-    static_assert(!MF || (H <= 16 && Q == 4), "matrix-pipe o_pair: 8 waves = 4 queries x 2 channel halves");
+                                                    const unsigned* __restrict__ pmax, unsigned long long* ts) {
+    // NT threads: 512 (Q = 4), or 1024 with the matrix-pipe o_pair and Q = 8 -- two waves per query there, and every K / V value
+    // fetched from L2 then serves eight queries: the logits and o / o_pt phases are bound by the CU's L2 read path (~35 B/clk)
+    constexpr int NT = MF ? 128 * Q : 512;
+    constexpr int CP = 128, HC = H * C, NQP = H * PQ * 3, NPT = H * PV * 3, NCAT = HC + H * PV * 4 + H * CP, HH = H / (NT / 256);
+    static_assert(H % (NT / 256) == 0 && C % 4 == 0 && HC + NPT <= 512 && (NT == 512 || NT == 1024), "shape");
+    static_assert(!MF || H <= 16, "matrix-pipe o_pair: 2 Q waves = Q queries x 2 channel halves");
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int NP8 = (N + 7) & ~7;
     float* att = sm;                            // [Q][H][NP8], zero padded
@@ -1164,14 +1167,19 @@ __global__ __launch_bounds__(512) void k_ipa_attn_q(const float* __restrict__ pr
     const int bid = rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
     const int b = bid / groups, i0 = (bid % groups) * Q;
     const int nq = min(Q, N - i0);
-    for (int u = tid; u < Q * HC; u += 512) { const int q = u / HC; sq[u] = proj[(size_t)(b * N + min(i0 + q, N - 1)) * ldp + (u - q * HC)]; }
-    for (int u = tid; u < Q * NQP; u += 512) { const int q = u / NQP; sqp[u] = qp[(size_t)(b * N + min(i0 + q, N - 1)) * NQP + (u - q * NQP)]; }
+    int ts_n = 0;                                  // developer aid (GENIE_SR_TS=1): s_memtime at the phase boundaries of work-group 0
+    auto stamp = [&]() { if (ts && blockIdx.x == 0 && tid == 0) ts[ts_n++] = __builtin_amdgcn_s_memtime(); };
+    stamp();
+    if (ts && tid == 0 && (blockIdx.x & 63) == 0) ts[16 + (blockIdx.x >> 6)] = __builtin_amdgcn_s_memtime();     // start of work-groups 0, 64, ...
+    for (int u = tid; u < Q * HC; u += NT) { const int q = u / HC; sq[u] = proj[(size_t)(b * N + min(i0 + q, N - 1)) * ldp + (u - q * HC)]; }
+    for (int u = tid; u < Q * NQP; u += NT) { const int q = u / NQP; sqp[u] = qp[(size_t)(b * N + min(i0 + q, N - 1)) * NQP + (u - q * NQP)]; }
     if (tid < H) {
         const float g = head_w[tid];
         const float sp = (g > 20.f) ? g : log1pf(expf(g));
         shw[tid] = sp * sqrtf(1.0f / (3.0f * ((float)PQ * 9.0f / 2.0f)));
     }
     __syncthreads();
+    stamp();
     const float s_qk = sqrtf(1.0f / (3.0f * (float)C)), s_b = sqrtf(1.0f / 3.0f);
     {
         const int hg = tid >> 8;                 // heads hg*HH .. hg*HH + HH - 1
@@ -1221,30 +1229,60 @@ __global__ __launch_bounds__(512) void k_ipa_attn_q(const float* __restrict__ pr
         }
     }
     __syncthreads();
-    for (int rr = wave; rr < Q * H; rr += 8) {
-        float* ar = att + rr * NP8;
-        float mx = -3.0e38f;
-        for (int j = lane; j < N; j += 64) mx = fmaxf(mx, ar[j]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        float s = 0.f;
-        for (int j = lane; j < N; j += 64) { const float e = expf(ar[j] - mx); ar[j] = e; s += e; }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        for (int j = lane; j < NP8; j += 64) ar[j] = (j < N) ? ar[j] / s : 0.f;
+    stamp();
+    // softmax over j: 16 lanes per row (four rows per wave and round), float4 passes over LDS, reductions as four DPP steps
+    // within the 16-lane row -- the one-wave-per-row form spent 12 dependent ds_bpermute round trips per row
+    {
+        auto dpp = [](float m, auto ctrl_tag) {
+            constexpr int CTRL = decltype(ctrl_tag)::value;
+            return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), CTRL, 0xf, 0xf, false));
+        };
+        const int l16 = lane & 15;
+        for (int rr = wave * 4 + (lane >> 4); rr < Q * H; rr += NT / 16) {
+            float* ar = att + rr * NP8;
+            float mx = -3.0e38f;
+            for (int j = 4 * l16; j < NP8; j += 64) {
+                const float4 v = *reinterpret_cast<const float4*>(ar + j);
+                mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+            }
+            mx = fmaxf(mx, dpp(mx, std::integral_constant<int, 0xB1>{})); mx = fmaxf(mx, dpp(mx, std::integral_constant<int, 0x4E>{}));
+            mx = fmaxf(mx, dpp(mx, std::integral_constant<int, 0x124>{})); mx = fmaxf(mx, dpp(mx, std::integral_constant<int, 0x128>{}));
+            float sum = 0.f;
+            for (int j = 4 * l16; j < NP8; j += 64) {
+                float4 v = *reinterpret_cast<const float4*>(ar + j);
+                v.x = expf(v.x - mx); v.y = expf(v.y - mx); v.z = expf(v.z - mx); v.w = expf(v.w - mx);     // padding (-3e38) -> 0
+                *reinterpret_cast<float4*>(ar + j) = v;
+                sum += (v.x + v.y) + (v.z + v.w);
+            }
+            sum += dpp(sum, std::integral_constant<int, 0xB1>{}); sum += dpp(sum, std::integral_constant<int, 0x4E>{});
+            sum += dpp(sum, std::integral_constant<int, 0x124>{}); sum += dpp(sum, std::integral_constant<int, 0x128>{});
+            for (int j = 4 * l16; j < NP8; j += 64) {
+                float4 v = *reinterpret_cast<const float4*>(ar + j);
+                v.x /= sum; v.y /= sum; v.z /= sum; v.w /= sum;
+                *reinterpret_cast<float4*>(ar + j) = v;
+            }
+        }
     }
     __syncthreads();
-    // o and o_pt: one output column per thread, Q accumulators, j unrolled x8
-    if (tid < HC + NPT) {
-        const bool isv = tid < HC;
-        const int w = isv ? tid : tid - HC;
-        const int hh = isv ? (tid / C) : (w / (PV * 3));
-        const float* vv = isv ? v + (size_t)b * N * HC + tid : vp + (size_t)b * N * NPT + w;
+    stamp();
+    // o and o_pt: one output column per thread, Q accumulators, j unrolled x8.  With 1024 threads the two halves of the
+    // work-group take the two halves of the j range (the loop is a chain of L2 round trips: twice the loads in flight) and
+    // leave their partial sums in LDS; they are added where they are consumed, after the barrier that follows o_pair.
+    constexpr int PARTS = NT / 512;
+    float* osum = opt + Q * NPT;                // [PARTS][Q][HC + NPT]   (PARTS = 2 only)
+    if ((tid & 511) < HC + NPT) {
+        const int part = tid >> 9, col = tid & 511;
+        const bool isv = col < HC;
+        const int w = isv ? col : col - HC;
+        const int hh = isv ? (col / C) : (w / (PV * 3));
+        const float* vv = isv ? v + (size_t)b * N * HC + col : vp + (size_t)b * N * NPT + w;
         const int ld = isv ? HC : NPT;
+        const int jmid = PARTS == 2 ? ((NP8 / 2 + 7) & ~7) : NP8;
+        const int jb = part ? jmid : 0, je = part ? NP8 : jmid;
         float acc[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) acc[q] = 0.f;
-        for (int j0 = 0; j0 < NP8; j0 += 8) {
+        for (int j0 = jb; j0 < je; j0 += 8) {
             float x[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) x[k] = vv[(size_t)min(j0 + k, N - 1) * ld];
@@ -1258,12 +1296,14 @@ __global__ __launch_bounds__(512) void k_ipa_attn_q(const float* __restrict__ pr
         }
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-            if (q < nq) {
-                if (isv) cat[(size_t)(b * N + i0 + q) * NCAT + tid] = acc[q];
+            if (PARTS == 2) osum[(part * Q + q) * (HC + NPT) + col] = acc[q];
+            else if (q < nq) {
+                if (isv) cat[(size_t)(b * N + i0 + q) * NCAT + col] = acc[q];
                 else opt[q * NPT + w] = acc[q];
             }
         }
     }
+    stamp();
     if constexpr (MF) {
         const int q = wave >> 1, hc = wave & 1, m = lane & 15, g = lane >> 4;
         if (q < nq) {
@@ -1372,9 +1412,19 @@ __global__ __launch_bounds__(512) void k_ipa_attn_q(const float* __restrict__ pr
         __syncthreads();
     }
     }
+    stamp();
+    if constexpr (PARTS == 2) {                 // (after the barrier at the end of the o_pair branch)
+        for (int u = tid; u < nq * (HC + NPT); u += NT) {
+            const int q = u / (HC + NPT), col = u - q * (HC + NPT);
+            const float sum = osum[q * (HC + NPT) + col] + osum[(Q + q) * (HC + NPT) + col];
+            if (col < HC) cat[(size_t)(b * N + i0 + q) * NCAT + col] = sum;
+            else opt[q * NPT + (col - HC)] = sum;
+        }
+        __syncthreads();
+    }
     {
         constexpr int np = H * PV;
-        for (int u = tid; u < nq * np; u += 512) {
+        for (int u = tid; u < nq * np; u += NT) {
             const int q = u / np, w = u - q * np;
             const int row = b * N + i0 + q;
             const float* R = rots + (size_t)row * 9;
@@ -1441,13 +1491,16 @@ static bool ipa_is_base(const genie_dims_t& d) {
 static size_t ipa_attn_t1_lds(const genie_dims_t& d, int N) {      // k_ipa_attn_t<12, 16, 4, 8> (single query; long structures)
     return ((size_t)d.n_head_ipa * ((N + 7) & ~7) + 4 * d.n_head_ipa * d.c_p + d.n_head_ipa * d.n_v_point * 3) * sizeof(float);
 }
-static size_t ipa_attn_q_lds(const genie_dims_t& d, int N, bool mf = false);
+#define IPA_Q8 8             // queries per work-group of the 1024-thread matrix-pipe form
+static size_t ipa_attn_q_lds(const genie_dims_t& d, int N, bool mf = false, int Q = IPA_Q);
 static bool ipa_use_q(const genie_dims_t& d, int N) { return ipa_attn_q_lds(d, N) <= 160 * 1024; }
+static bool ipa_use_q8(const genie_dims_t& d, int N) { return ipa_attn_q_lds(d, N, true, IPA_Q8) <= 160 * 1024 && getenv("GENIE_IPA_Q8"); }
 static size_t ipa_attn_t_lds(const genie_dims_t& d, int N) { return ipa_use_q(d, N) ? ipa_attn_q_lds(d, N) : ipa_attn_t1_lds(d, N); }
-static size_t ipa_attn_q_lds(const genie_dims_t& d, int N, bool mf) {   // k_ipa_attn_q<12, 16, 4, 8, IPA_Q, mf>: no reduction buffer with mf
+static size_t ipa_attn_q_lds(const genie_dims_t& d, int N, bool mf, int Q) {   // k_ipa_attn_q<12, 16, 4, 8, Q, mf>: no reduction buffer with mf
     const size_t H = d.n_head_ipa;
-    return ((size_t)IPA_Q * H * ((N + 7) & ~7) + IPA_Q * H * d.c_hidden_ipa + IPA_Q * H * d.n_qk_point * 3 + 16 +
-            IPA_Q * H * d.n_v_point * 3 + (mf ? 0 : 4 * H * d.c_p)) * sizeof(float);
+    return ((size_t)Q * H * ((N + 7) & ~7) + Q * H * d.c_hidden_ipa + Q * H * d.n_qk_point * 3 + 16 +
+            Q * H * d.n_v_point * 3 + (mf ? 0 : 4 * H * d.c_p) +
+            (mf && Q == IPA_Q8 ? 2 * Q * H * (d.c_hidden_ipa + 3 * d.n_v_point) : 0)) * sizeof(float);
 }
 size_t ipa_attn_lds(const genie_dims_t& d, int N) {
     if (ipa_is_base(d)) return ipa_attn_t_lds(d, N);
@@ -1467,14 +1520,29 @@ void launch_ipa_attn(genie_ctx* h, hipStream_t st, int layer, const float* head_
     if (ipa_is_base(d)) {
         const dim3 grid(h->B * ((h->N + IPA_Q - 1) / IPA_Q));
         const int rev = (int)((layer ^ h->hx_launches ^ 1) & 1);
-        if (h->hx)
+        static unsigned long long* ts = nullptr;
+        if (!ts && getenv("GENIE_SR_TS")) hipMalloc((void**)&ts, 64 * sizeof(unsigned long long));
+        if (h->hx && ipa_use_q8(d, h->N))
+            hipLaunchKernelGGL((k_ipa_attn_q<12, 16, 4, 8, IPA_Q8, 1>), dim3(h->B * ((h->N + IPA_Q8 - 1) / IPA_Q8)), dim3(1024),
+                               ipa_attn_q_lds(d, h->N, true, IPA_Q8), st, h->proj, ldp, h->kT, h->v, h->qp, h->kpT, h->vp, h->ipa_bias, h->p,
+                               h->rots_w, h->trans_w, h->rmaskf, head_w, h->cat, h->B, h->N, layer, rev, h->pmax, ts);
+        else if (h->hx)
             hipLaunchKernelGGL((k_ipa_attn_q<12, 16, 4, 8, IPA_Q, 1>), grid, dim3(512), ipa_attn_q_lds(d, h->N, true), st, h->proj, ldp,
                                h->kT, h->v, h->qp, h->kpT, h->vp, h->ipa_bias, h->p, h->rots_w, h->trans_w, h->rmaskf, head_w, h->cat,
-                               h->B, h->N, layer, rev, h->pmax);
+                               h->B, h->N, layer, rev, h->pmax, ts);
         else
             hipLaunchKernelGGL((k_ipa_attn_q<12, 16, 4, 8, IPA_Q, 0>), grid, dim3(512), ipa_attn_q_lds(d, h->N), st, h->proj, ldp,
                                h->kT, h->v, h->qp, h->kpT, h->vp, h->ipa_bias, h->p, h->rots_w, h->trans_w, h->rmaskf, head_w, h->cat,
-                               h->B, h->N, layer, rev, h->pmax);
+                               h->B, h->N, layer, rev, h->pmax, ts);
+        if (ts) {
+            unsigned long long v[24] = {0};
+            hipStreamSynchronize(st);
+            hipMemcpy(v, ts, sizeof(v), hipMemcpyDeviceToHost);
+            fprintf(stderr, "ipa_attn wg0 (cycles): q-load %llu logits %llu softmax %llu o/o_pt %llu o_pair %llu total %llu; starts of wg 64k:", v[1] - v[0],
+                    v[2] - v[1], v[3] - v[2], v[4] - v[3], v[5] - v[4], v[5] - v[0]);
+            for (int k = 0; k < 8; ++k) fprintf(stderr, " %lld", (long long)(v[16 + k] - v[0]));
+            fprintf(stderr, "\n");
+        }
         return;
     }
     hipLaunchKernelGGL(k_ipa_attn, dim3(h->B * h->N), dim3(256), ipa_attn_lds(d, h->N), st, h->proj, ldp, h->kT, h->v, h->qp,
@@ -1561,6 +1629,9 @@ void single_kernels_init(const genie_dims_t& d, int n_max) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipa_attn_q_lds(d, n_max));
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn_q<12, 16, 4, 8, IPA_Q, 1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipa_attn_q_lds(d, n_max, true));
+            if (ipa_use_q8(d, n_max))
+                hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn_q<12, 16, 4, 8, IPA_Q8, 1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipa_attn_q_lds(d, n_max, true, IPA_Q8));
         } else
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn_t<12, 16, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)ipa_attn_t1_lds(d, n_max));
