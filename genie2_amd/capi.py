@@ -39,7 +39,7 @@ class GenieFeatures(C.Structure):
 
 
 class GenieTaps(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ('s', 'p', 's_final', 'rots_out', 'trans_out', 'p_init', 'p_layer0')]
+    _fields_ = [(k, C.c_void_p) for k in ('s', 'p', 's_final', 'rots_out', 'trans_out', 'p_init', 'p_layer0', 'states')]
 
 
 # name -> (restype, argtypes); every symbol include/genie_hip.h declares

@@ -579,6 +579,8 @@ static int denoise_internal(genie_ctx* h, hipStream_t st, const float* trans, co
     // structure net
     launch_ipa_bias(h, st);
     HIP_TRY(h, d2d(h->s, h->s0, (size_t)M * cs * 4));
+    if (taps && taps->states) HIP_TRY(h, d2d(taps->states, h->s0, (size_t)M * cs * 4));
+    int n_state = 1;
     const int nproj = ipa_proj_n(d), ncat = ipa_cat_n(d);
     for (int blk = 0; blk < d.n_structure_block; ++blk) {
         for (int l = 0; l < d.n_structure_layer; ++l) {
@@ -587,7 +589,10 @@ static int denoise_internal(genie_ctx* h, hipStream_t st, const float* trans, co
             launch_gemm_rows(h, st, h->s, cs, M, cs, S.proj_w, nproj, S.proj_b, nullptr, 0, nullptr, 0, h->proj, nproj);
             launch_ipa_prep(h, st);
             launch_ipa_attn(h, st, l, S.head_w);
-            if (launch_struct_tail(h, st, S, last ? trans : nullptr, last ? z_out : nullptr)) continue;
+            auto state_tap = [&]() -> hipError_t {
+                return (taps && taps->states) ? d2d(taps->states + (size_t)(n_state++) * M * cs, h->s, (size_t)M * cs * 4) : hipSuccess;
+            };
+            if (launch_struct_tail(h, st, S, last ? trans : nullptr, last ? z_out : nullptr)) { HIP_TRY(h, state_tap()); continue; }
             launch_gemm_rows(h, st, h->cat, ncat, M, ncat, S.out_w, cs, S.out_b, h->s, cs, nullptr, 0, h->s1, cs);
             launch_layernorm_rows(h, st, h->s1, h->s2, M, cs, S.ln_ipa_g, S.ln_ipa_b);
             launch_gemm_rows(h, st, h->s2, cs, M, cs, S.t1_w, cs, S.t1_b, nullptr, 0, nullptr, 1, h->h1, cs);
@@ -595,6 +600,7 @@ static int denoise_internal(genie_ctx* h, hipStream_t st, const float* trans, co
             launch_gemm_rows(h, st, h->h2, cs, M, cs, S.t3_w, cs, S.t3_b, h->s2, cs, nullptr, 0, h->s1, cs);
             launch_layernorm_rows(h, st, h->s1, h->s, M, cs, S.ln_tr_g, S.ln_tr_b);
             launch_bb_update(h, st, S, last ? trans : nullptr, last ? z_out : nullptr);
+            HIP_TRY(h, state_tap());
         }
     }
     if (taps && taps->s_final) HIP_TRY(h, d2d(taps->s_final, h->s, (size_t)M * cs * 4));

@@ -106,7 +106,8 @@ class GenieEngine:
         z = torch.empty(B, N, 3, device=self.device)
         shapes = {'s': (B, N, self.dims['c_s']), 'p': (B, N, N, self.dims['c_p']), 's_final': (B, N, self.dims['c_s']),
                   'rots_out': (B, N, 3, 3), 'trans_out': (B, N, 3), 'p_init': (B, N, N, self.dims['c_p']),
-                  'p_layer0': (B, N, N, self.dims['c_p'])}
+                  'p_layer0': (B, N, N, self.dims['c_p']),
+                  'states': (1 + self.dims['n_structure_block'] * self.dims['n_structure_layer'], B, N, self.dims['c_s'])}
         out = {k: torch.empty(shapes[k], device=self.device) for k in taps}
         ct = capi.GenieTaps(**{k: v.data_ptr() for k, v in out.items()})
         rc = self.lib.genie_denoise(self._h, self._stream(), _ptr(trans), _ptr(rots), _ptr(ts), _ptr(codes), _ptr(z),

@@ -89,14 +89,14 @@ class Denoiser(nn.Module):
 
     def forward(self, ts, timesteps, features, outputs=('z',), quat_codes=None):
         """Returns a dict with 'z' [B,N,3] (what the samplers consume) and, when
-        named in `outputs`, 's', 'p', 'states' ([2,B,N,c_s]: first and last of
-        the reference's list) and 'ts' (updated frames)."""
+        named in `outputs`, 's', 'p', 'states' ([1 + blocks * layers, B, N, c_s]
+        as structure_net.py:236-243) and 'ts' (updated frames)."""
         eng = self.bind(features)
         taps = set()
-        if 's' in outputs or 'states' in outputs:
+        if 's' in outputs:
             taps.add('s')
         if 'states' in outputs:
-            taps.add('s_final')
+            taps.add('states')
         if 'p' in outputs:
             taps.add('p')
         if 'ts' in outputs:
@@ -109,7 +109,7 @@ class Denoiser(nn.Module):
         if 'p' in outputs:
             out['p'] = raw['p']
         if 'states' in outputs:
-            out['states'] = torch.stack([raw['s'], raw['s_final']])
+            out['states'] = raw['states']
         if 'ts' in outputs:
             out['ts'] = T(raw['rots_out'], raw['trans_out'])
         return out

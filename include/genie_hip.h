@@ -80,6 +80,7 @@ typedef struct {
     float* trans_out;  /* [B,N,3]        'ts'.trans                            */
     float* p_init;     /* [B,N,N,c_p]    pair feature net output (test tap)    */
     float* p_layer0;   /* [B,N,N,c_p]    after pair transform layer 0 (tap)    */
+    float* states;     /* [1+blocks*layers,B,N,c_s] 'states' (structure_net.py:236-243) */
 } genie_taps_t;
 
 /* ---- lifetime ---------------------------------------------------------- */

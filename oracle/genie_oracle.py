@@ -476,6 +476,7 @@ def backbone_update(sd, pfx, s):
 def structure_net(sd, dims, s, p, rots, trans, features, taps=None):
     """structure_net.py:76-116,189-243 and modules/structure_transition.py:34-70."""
     mask = features['residue_mask'].float()
+    states = [s]                                         # structure_net.py:236-243: input + s after every layer
     for _ in range(dims['n_structure_block']):
         for l in range(dims['n_structure_layer']):
             pfx = f'structure_net.net.{l}.'
@@ -489,9 +490,12 @@ def structure_net(sd, dims, s, p, rots, trans, features, taps=None):
             s = _ln(sd, pfx + 'transition.layer_norm', s)
             if taps is not None and l == 0:
                 taps['s_after_layer0'] = s
+            states.append(s)
             r_upd, t_upd = backbone_update(sd, pfx + 'bb_update.', s)
             trans = rot_vec_mul(rots, t_upd) + trans       # affine_utils.py:109-116
             rots = rot_matmul(rots, r_upd)
+    if taps is not None:
+        taps['states'] = torch.stack(states)
     return s, rots, trans
 
 

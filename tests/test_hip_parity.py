@@ -91,7 +91,7 @@ def test_denoiser_call_matches_reference_golden(case, math_engine):
     ts = torch.full((B,), int(g['timestep']), dtype=torch.int32)
     base_engine.bind_features(f)
     out = base_engine.denoise(t(g['trans']), t(g['rots']), ts, t(g['quat_codes']),
-                              taps=('s', 'p', 's_final', 'rots_out', 'trans_out', 'p_init', 'p_layer0'))
+                              taps=('s', 'p', 's_final', 'rots_out', 'trans_out', 'p_init', 'p_layer0', 'states'))
     m = f['residue_mask'].unsqueeze(-1).float()
     zref = t(g['z'])
     assert mdiff(out['z'].cpu() * m, zref * m) <= 1e-4 * max(1.0, float(zref.abs().max()))
@@ -102,6 +102,10 @@ def test_denoiser_call_matches_reference_golden(case, math_engine):
         assert mdiff(got, t(g[key])) <= 2e-4 * max(1.0, float(np.abs(g[key]).max())), key
     assert abs(float(out['p'].abs().mean()) - float(g['p_final_abs_mean'])) < 1e-4 * float(g['p_final_abs_mean'])
     assert mdiff(out['s_final'].cpu() * m, t(g['states'])[1] * m) < 2e-3
+    # the golden keeps states[[1, -1]] of the reference's stack: after the first structure layer and after the last
+    st = out['states'].cpu()
+    assert torch.equal(st[0], out['s'].cpu()) and torch.equal(st[-1], out['s_final'].cpu())
+    assert mdiff(st[1] * m, t(g['states'])[0] * m) < 2e-3
     m4 = m.unsqueeze(-1)
     assert mdiff(out['rots_out'].cpu() * m4, t(g['rots_out']) * m4) < 1e-3
     assert mdiff(out['trans_out'].cpu() * m, t(g['trans_out']) * m) <= 1e-4 * max(1.0, float(np.abs(g['trans_out']).max()))
@@ -168,9 +172,12 @@ def test_denoiser_matches_oracle_small_dims(name, rescale, math):
     ref = O.denoiser_forward(sd, dims, rots, trans, ts, f, 'closed', None, taps)
     eng = GenieEngine(dims, sd, 'cuda:0', math=math)
     eng.bind_features(f)
-    out = eng.denoise(trans, rots, ts, None, taps=('s', 'p', 'p_init'))
+    out = eng.denoise(trans, rots, ts, None, taps=('s', 'p', 'p_init', 'states'))
     m = fr['residue_mask'].unsqueeze(-1).float()
     assert mdiff(out['s'], ref['s']) < 2e-5
+    # 'states' (structure_net.py:236-243): the single representation entering the structure net and after each of its layers
+    assert out['states'].shape == taps['states'].shape == (1 + dims['n_structure_layer'], B, N, dims['c_s'])
+    assert mdiff(out['states'].cpu() * m, taps['states'] * m) <= 1e-4 * max(1.0, float(taps['states'].abs().max()))
     assert mdiff(out['p_init'], taps['p_init']) <= 1e-4 * max(1.0, float(taps['p_init'].abs().max()))
     assert mdiff(out['p'], ref['p']) <= 1e-4 * max(1.0, float(ref['p'].abs().max()))
     assert mdiff(out['z'].cpu() * m, ref['z'] * m) <= 1e-4 * max(1.0, float(ref['z'].abs().max()))
@@ -343,7 +350,7 @@ def test_sampler_api_end_to_end(tmp_path, base_weights):
     x = noise[0, :1].cuda()
     rots = model.model.bind(feats).frenet(x)
     out = model.model(T(rots, x), torch.tensor([20], dtype=torch.int32), feats, outputs=('z', 's', 'p', 'states', 'ts'))
-    assert out['z'].shape == (1, 30, 3) and out['p'].shape == (1, 30, 30, 128) and out['states'].shape == (2, 1, 30, 384)
+    assert out['z'].shape == (1, 30, 3) and out['p'].shape == (1, 30, 30, 128) and out['states'].shape == (9, 1, 30, 384)
     assert out['ts'].rots.shape == (1, 30, 3, 3)
 
 
