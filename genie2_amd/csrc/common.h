@@ -268,7 +268,7 @@ void prof_begin(genie_ctx* h, hipStream_t st, int cls);
 void prof_end(genie_ctx* h, hipStream_t st);
 
 struct ProfScope {
-    genie_ctx* h; hipStream_t st;
-    ProfScope(genie_ctx* h_, hipStream_t st_, int cls) : h(h_), st(st_) { if (h->prof) prof_begin(h, st, cls); }
-    ~ProfScope() { if (h->prof) prof_end(h, st); }
+    genie_ctx* h; hipStream_t st; bool on;
+    ProfScope(genie_ctx* h_, hipStream_t st_, int cls, bool enable = true) : h(h_), st(st_), on(enable && h_->prof) { if (on) prof_begin(h, st, cls); }
+    ~ProfScope() { if (on) prof_end(h, st); }
 };

@@ -763,25 +763,84 @@ static int hx_num_cu() {
     return g_hx_cu;
 }
 static int hx_nw() { return 8; }   // waves per work-group (one work-group per CU: 130 KiB of LDS)
-static unsigned hx_grid(long long n_tiles, int nw) {
-    const long long cap = (nw == 8 ? 1LL : 2LL) * hx_num_cu();
+// `cus`: CUs this launch may fill (all of them, or half when two halves of the batch run side by side)
+static unsigned hx_grid(long long n_tiles, int nw, int cus) {
+    const long long cap = (nw == 8 ? 1LL : 2LL) * cus;
     return (unsigned)(n_tiles < cap ? n_tiles : cap);
 }
 
-void launch_pair_transition_hx(genie_ctx* h, hipStream_t st, const PairLayerW& w) {
-    const long long M = (long long)h->B * h->N * h->N;
+// A contiguous slice of the batch (structures b0 .. b0 + nb - 1) on its own stream: every pair-stack kernel is separable over
+// the batch (outermost dimension of p, a, b, x and of the mask), so a slice is a pointer offset and a smaller tile count.
+struct HxSlice { int b0, nb; hipStream_t st; int cus; unsigned launches; bool prof; };
+
+static void pair_transition_slice(genie_ctx* h, HxSlice& v, const PairLayerW& w) {
+    const int N = h->N;
+    const long long M = (long long)v.nb * N * N;
     const long long n_wt = (M + 31) / 32;
     const int n_hb = h->d.pair_transition_n * 4;
     const HxTransW& x = w.hx_pt;
-    hipLaunchKernelGGL(k_pair_transition_hx<8>, dim3(hx_grid((n_wt + 7) / 8, 8)), dim3(512), HX_LDS_BYTES, st, h->p, h->rmaskf,
-                       x.img, x.b1s, x.b2s, h->N, M, n_hb, x.sx, x.c1, x.c2, (int)(h->hx_launches++ & 1));
+    hipLaunchKernelGGL(k_pair_transition_hx<8>, dim3(hx_grid((n_wt + 7) / 8, 8, v.cus)), dim3(512), HX_LDS_BYTES, v.st,
+                       h->p + (size_t)v.b0 * N * N * 128, h->rmaskf + (size_t)v.b0 * N, x.img, x.b1s, x.b2s, N, M, n_hb, x.sx, x.c1, x.c2,
+                       (int)(v.launches++ & 1));
 }
 
-// GENIE_HX_SLICE=n runs the three kernels of a triangle multiplication per slice of n structures, reusing
-// the same a / b / x buffers, so that (n = 2, N = 256: a + b + x = 201 MB) the operands stay in the
-// 256-MiB Infinity Cache between producer and consumer.  Measured: no gain (82.1 / 80.4 / 83.0 / 80.9
-// batch-steps/s for n = 8 / 4 / 2 / 1) -- these kernels are limited by the per-CU vector-memory pipe,
-// not by HBM bandwidth -- so the default is the whole batch; kept as a switch for larger N.
+static void trimul_slice(genie_ctx* h, HxSlice& v, const TriMulW& w, bool outgoing) {
+    const int N = h->N, NP = h->NP, ntile = (N + 31) / 32;
+    const int nw = hx_nw();
+    const HxTriW& x = w.hx;
+    const size_t cm_off = (size_t)v.b0 * 128 * NP * NP;
+    unsigned* acm = reinterpret_cast<unsigned*>(h->acm) + cm_off;
+    unsigned* bcm = reinterpret_cast<unsigned*>(h->bcm) + cm_off;
+    float* xcm = h->xcm + cm_off;
+    const int n_wt = v.nb * N * ntile;
+    const unsigned cm_bytes = (unsigned)((size_t)v.nb * 128 * NP * NP * 4);
+    const unsigned z_bytes = (unsigned)((size_t)v.nb * N * N * 512);
+    float* zs = h->p + (size_t)v.b0 * N * N * 128;
+    const float* ms = h->rmaskf + (size_t)v.b0 * N;
+    hipStream_t st = v.st;
+    {
+        ProfScope ps(h, st, KC_TRIMUL_PROJ, v.prof);
+        const dim3 grid(hx_grid((n_wt + nw - 1) / nw, nw, v.cus)), block(nw * 64);
+        const int rev = (int)(v.launches++ & 1);
+#define HX_PROJ(OUT, NWV) hipLaunchKernelGGL((k_trimul_proj_hx<OUT, NWV>), grid, block, HX_LDS_BYTES, st, zs, ms, x.img_proj, \
+                                             x.bias_proj, acm, bcm, N, NP, n_wt, cm_bytes, z_bytes, x.sx, x.cpa, x.cpb, x.cg, rev)
+        if (outgoing) HX_PROJ(true, 8);
+        else HX_PROJ(false, 8);
+#undef HX_PROJ
+    }
+    {
+        ProfScope ps(h, st, KC_TRIMUL_CONTRACT, v.prof);
+        const int BC = v.nb * h->d.c_hidden_mul;
+        const int ncu = v.cus;
+        const int rev = (int)(v.launches++ & 1);
+        if (NP >= 128) {
+            const int tiles = (NP + 127) / 128;
+            const int n_tiles = tiles * tiles * ((BC + 7) / 8) * 8;
+            hipLaunchKernelGGL(k_trimul_contract_hx<2>, dim3(n_tiles < 3 * ncu ? n_tiles : 3 * ncu), dim3(256), 2 * 4 * 128 * CX_ROWB, st,
+                               acm, bcm, xcm, NP, BC, cm_bytes, x.cx, rev);
+        } else {
+            const int tiles = (NP + 63) / 64;
+            const int n_tiles = tiles * tiles * ((BC + 7) / 8) * 8;
+            hipLaunchKernelGGL(k_trimul_contract_hx<1>, dim3(n_tiles < 4 * ncu ? n_tiles : 4 * ncu), dim3(256), 2 * 4 * 64 * CX_ROWB, st,
+                               acm, bcm, xcm, NP, BC, cm_bytes, x.cx, rev);
+        }
+    }
+    {
+        ProfScope ps(h, st, KC_TRIMUL_OUT, v.prof);
+        hipLaunchKernelGGL(k_trimul_out_hx<8>, dim3(hx_grid((n_wt + 7) / 8, 8, v.cus)), dim3(512), HX_LDS_BYTES, st, zs, xcm, x.img_out,
+                           x.bgs, x.bzs, N, NP, n_wt, cm_bytes, z_bytes, x.sx, x.cgo, x.cz, (int)(v.launches++ & 1));
+    }
+}
+
+void launch_pair_transition_hx(genie_ctx* h, hipStream_t st, const PairLayerW& w) {
+    HxSlice v{0, h->B, st, hx_num_cu(), h->hx_launches, h->prof};
+    pair_transition_slice(h, v, w);
+    h->hx_launches = v.launches;
+}
+
+// GENIE_HX_SLICE=n runs the three kernels of a triangle multiplication per slice of n structures, so that (n = 2, N = 256:
+// a + b + x = 201 MB) the operands stay in the 256-MiB Infinity Cache between producer and consumer.  Measured: no gain
+// (82.1 / 80.4 / 83.0 / 80.9 batch-steps/s for n = 8 / 4 / 2 / 1), so the default is the whole batch; kept as a switch for larger N.
 static int g_hx_slice = 0;
 static int hx_slice() {
     if (!g_hx_slice) { const char* e = getenv("GENIE_HX_SLICE"); g_hx_slice = e && atoi(e) > 0 ? atoi(e) : 1 << 20; }
@@ -789,53 +848,18 @@ static int hx_slice() {
 }
 
 void launch_trimul_hx(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgoing) {
-    const int N = h->N, NP = h->NP, ntile = (N + 31) / 32;
-    const int nw = hx_nw();
-    const HxTriW& x = w.hx;
-    unsigned* acm = reinterpret_cast<unsigned*>(h->acm);
-    unsigned* bcm = reinterpret_cast<unsigned*>(h->bcm);
     const int SB = hx_slice();
     for (int b0 = 0; b0 < h->B; b0 += SB) {
-        const int nb = h->B - b0 < SB ? h->B - b0 : SB;
-        const int n_wt = nb * N * ntile;
-        const unsigned cm_bytes = (unsigned)((size_t)nb * 128 * NP * NP * 4);
-        const unsigned z_bytes = (unsigned)((size_t)nb * N * N * 512);
-        float* zs = h->p + (size_t)b0 * N * N * 128;
-        const float* ms = h->rmaskf + (size_t)b0 * N;
-        {
-            ProfScope ps(h, st, KC_TRIMUL_PROJ);
-            const dim3 grid(hx_grid((n_wt + nw - 1) / nw, nw)), block(nw * 64);
-            const int rev = (int)(h->hx_launches++ & 1);
-#define HX_PROJ(OUT, NWV) hipLaunchKernelGGL((k_trimul_proj_hx<OUT, NWV>), grid, block, HX_LDS_BYTES, st, zs, ms, x.img_proj, \
-                                             x.bias_proj, acm, bcm, N, NP, n_wt, cm_bytes, z_bytes, x.sx, x.cpa, x.cpb, x.cg, rev)
-            if (outgoing) HX_PROJ(true, 8);
-            else HX_PROJ(false, 8);
-#undef HX_PROJ
-        }
-        {
-            ProfScope ps(h, st, KC_TRIMUL_CONTRACT);
-            const int BC = nb * h->d.c_hidden_mul;
-            const int ncu = hx_num_cu();
-            const int rev = (int)(h->hx_launches++ & 1);
-            if (NP >= 128) {
-                const int tiles = (NP + 127) / 128;
-                const int n_tiles = tiles * tiles * ((BC + 7) / 8) * 8;
-                hipLaunchKernelGGL(k_trimul_contract_hx<2>, dim3(n_tiles < 3 * ncu ? n_tiles : 3 * ncu), dim3(256), 2 * 4 * 128 * CX_ROWB, st,
-                                   acm, bcm, h->xcm, NP, BC, cm_bytes, x.cx, rev);
-            } else {
-                const int tiles = (NP + 63) / 64;
-                const int n_tiles = tiles * tiles * ((BC + 7) / 8) * 8;
-                hipLaunchKernelGGL(k_trimul_contract_hx<1>, dim3(n_tiles < 4 * ncu ? n_tiles : 4 * ncu), dim3(256), 2 * 4 * 64 * CX_ROWB, st,
-                                   acm, bcm, h->xcm, NP, BC, cm_bytes, x.cx, rev);
-            }
-        }
-        {
-            ProfScope ps(h, st, KC_TRIMUL_OUT);
-            hipLaunchKernelGGL(k_trimul_out_hx<8>, dim3(hx_grid((n_wt + 7) / 8, 8)), dim3(512), HX_LDS_BYTES, st, zs, h->xcm, x.img_out,
-                               x.bgs, x.bzs, N, NP, n_wt, cm_bytes, z_bytes, x.sx, x.cgo, x.cz, (int)(h->hx_launches++ & 1));
-        }
+        HxSlice v{b0, h->B - b0 < SB ? h->B - b0 : SB, st, hx_num_cu(), h->hx_launches, h->prof};
+        trimul_slice(h, v, w, outgoing);
+        h->hx_launches = v.launches;
     }
 }
+
+// (Tried on top of the slices: the whole pair transform net with the batch in two halves on two streams, each on half of the
+//  CUs, the second half one or two kernels behind the first, so that a memory-bound TriMul kernel and the matrix-bound
+//  transition run side by side.  89.6 - 94.2 batch-steps/s against 95.1: a kernel on half of the CUs takes twice as long,
+//  whether it is bound by memory or by the matrix pipe.)
 
 void pair_hx_kernels_init() {
 #define HX_ATTR(k) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, HX_LDS_BYTES)
