@@ -419,7 +419,7 @@ int genie_load_weights(genie_handle_t h, const float* blob, size_t n_floats) {
         slot(&S.ln_tr_g, img.raw(lt_g, cs)); slot(&S.ln_tr_b, img.raw(lt_b, cs));
         slot(&S.bb_w, img.raw(bw, 6 * cs)); slot(&S.bb_b, img.raw(bbs, 6));
     }
-    slot(&h->ipa_bias_w, img.pack(wb_all.data(), (int)(d.n_structure_layer * H), (int)cp));
+    pack_gemm(&h->ipa_bias_w, wb_all.data(), (int)(d.n_structure_layer * H), (int)cp);    // f32 pack + hx image (k_ipa_bias_hx)
     slot(&h->ipa_bias_b, img.raw(bb_all.data(), bb_all.size()));
     if (c.left != 0) { SET_ERR(h, "genie_load_weights: %zu floats left over", c.left); return GENIE_E_ARG; }
 

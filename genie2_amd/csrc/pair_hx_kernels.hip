@@ -861,10 +861,105 @@ void launch_trimul_hx(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgo
 //  transition run side by side.  89.6 - 94.2 batch-steps/s against 95.1: a kernel on half of the CUs takes twice as long,
 //  whether it is bound by memory or by the matrix pipe.)
 
+// ---------------------------------------------------------------------------------------------
+// Pair bias of all IPA layers in one pass over p (invariant_point_attention.py:181), hx arithmetic:
+//   out[o][b][i][j] = sum_c W[o][c] p[b][i][j][c] + bias[o],  o = layer * H + head  (L H = 96 rows, three 32-row blocks).
+// The f32 form (pair_kernels.hip k_ipa_bias) staged p through LDS for 192 v_mfma_f32_32x32x2 per wave and tile.  Here a wave
+// takes 32 consecutive j of one (b, i): lane n = j holds its own row -- 8 consecutive channels per k-step are exactly the B
+// fragment of v_mfma_f32_32x32x16_f16 (k = 16 s + 8 (lane >> 5) + e), so p goes from HBM to the matrix pipe through
+// registers only (a 128-B line is used up by four consecutive k-steps of the same wave), the block-floating-point scale of
+// a row is an in-lane maximum plus one exchange with the lane holding the row's other channels, and it comes back out as a
+// per-column (= per-lane) factor.  W (48 KiB as 24 hx units) sits in LDS.  By-product: max |p| for the attention kernel's split.
+// ---------------------------------------------------------------------------------------------
+#define IB_UNITS 24          // 3 row blocks x 8 k-steps
+__global__ __launch_bounds__(256) void k_ipa_bias_hx(const float* __restrict__ z, const unsigned char* __restrict__ wimg, float inv_sw,
+                                                     const float* __restrict__ bias, float* __restrict__ out, int B, int N, int LH,
+                                                     int n_tiles, int rev, unsigned* pmax) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ibw[];          // [IB_UNITS][hi 1 KiB | lo 1 KiB], then bias[96]
+    float* sbias = reinterpret_cast<float*>(ibw + IB_UNITS * 2048);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int u = tid; u < IB_UNITS * 128; u += 256) reinterpret_cast<uint4*>(ibw)[u] = reinterpret_cast<const uint4*>(wimg)[u];
+    if (tid < 96) sbias[tid] = tid < LH ? bias[tid] : 0.f;
+    __syncthreads();
+    const int n = lane & 31, hf = lane >> 5;
+    const int jt = (N + 31) >> 5;                        // 32-wide j tiles per (b, i)
+    float amax = 0.f;
+    for (int t = blockIdx.x * 4 + wave; t < n_tiles; t += gridDim.x * 4) {
+        const int tt = rev ? n_tiles - 1 - t : t;
+        const int j0 = (tt % jt) * 32;
+        const int bi = tt / jt;                          // b * N + i
+        const int j = min(j0 + n, N - 1);
+        const float* row = z + ((size_t)bi * N + j) * 128 + 8 * hf;
+        float4 x[8][2];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            x[s][0] = *reinterpret_cast<const float4*>(row + 16 * s);
+            x[s][1] = *reinterpret_cast<const float4*>(row + 16 * s + 4);
+        }
+        float m = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(x[s][0].x), fabsf(x[s][0].y)), fmaxf(fabsf(x[s][0].z), fabsf(x[s][0].w))));
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(x[s][1].x), fabsf(x[s][1].y)), fmaxf(fabsf(x[s][1].z), fabsf(x[s][1].w))));
+        }
+        m = fmaxf(m, __shfl_xor(m, 32));                 // the row's other 64 channels
+        amax = fmaxf(amax, m);
+        const int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 255u);
+        const bool tiny = e < 16;
+        const float sc = tiny ? 1.0f : __builtin_bit_cast(float, (unsigned)(268 - e) << 23);      // max * sc in [2^14, 2^15)
+        const float isc = (tiny ? 1.0f : __builtin_bit_cast(float, (unsigned)(e - 14) << 23)) * inv_sw;
+        f32x16 acc[3];
+#pragma unroll
+        for (int blk = 0; blk < 3; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[blk][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float xs[8] = {x[s][0].x, x[s][0].y, x[s][0].z, x[s][0].w, x[s][1].x, x[s][1].y, x[s][1].z, x[s][1].w};
+            h8 bh, bl;
+            hx_split8(xs, sc, bh, bl);
+#pragma unroll
+            for (int blk = 0; blk < 3; ++blk) {
+                const h8 ah = hx_frag(ibw, blk * 8 + s, 0, lane), al = hx_frag(ibw, blk * 8 + s, 1, lane);
+                MFH3(ah, al, bh, bl, acc[blk]);
+            }
+        }
+        if (j0 + n < N) {
+            const int b = bi / N, i = bi - b * N;
+#pragma unroll
+            for (int blk = 0; blk < 3; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                    if (o < LH) out[((((size_t)o * B + b) * N + i) * N) + j0 + n] = fmaf(acc[blk][r], isc, sbias[o]);
+                }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if (lane == 0 && __float_as_uint(amax) > *reinterpret_cast<volatile unsigned*>(pmax)) atomicMax(pmax, __float_as_uint(amax));
+}
+
+bool launch_ipa_bias_hx(genie_ctx* h, hipStream_t st) {
+    const int LH = h->d.n_structure_layer * h->d.n_head_ipa;
+    if (!h->hx || LH > 96 || h->d.c_p != 128 || getenv("GENIE_IPA_BIAS_F32")) return false;
+    const HxGemmW* w = nullptr;
+    for (int i = 0; i < h->n_hxg; ++i)
+        if (h->hxg[i].w == h->ipa_bias_w) w = &h->hxg[i];
+    if (!w) return false;
+    const int N = h->N, n_tiles = h->B * N * ((N + 31) / 32);
+    const int grid = n_tiles / 4 < 2 * hx_num_cu() ? (n_tiles + 3) / 4 : 2 * hx_num_cu();      // 191 registers: two work-groups per CU
+    hipMemsetAsync(h->pmax, 0, sizeof(unsigned), st);
+    hipLaunchKernelGGL(k_ipa_bias_hx, dim3(grid), dim3(256), IB_UNITS * 2048 + 96 * 4, st, h->p, w->img, w->inv_s, h->ipa_bias_b, h->ipa_bias,
+                       h->B, N, LH, n_tiles, (int)(h->hx_launches & 1), h->pmax);
+    return true;
+}
+
 void pair_hx_kernels_init() {
 #define HX_ATTR(k) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, HX_LDS_BYTES)
     HX_ATTR((k_trimul_proj_hx<true, 8>)); HX_ATTR((k_trimul_proj_hx<false, 8>));
     HX_ATTR(k_trimul_out_hx<8>);
 #undef HX_ATTR
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_transition_hx<8>), hipFuncAttributeMaxDynamicSharedMemorySize, HX_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_bias_hx), hipFuncAttributeMaxDynamicSharedMemorySize, IB_UNITS * 2048 + 96 * 4);
 }

@@ -496,8 +496,10 @@ void launch_pair_transition(genie_ctx* h, hipStream_t st, const PairLayerW& w) {
     else launch_pair_transition_wl(h, st, w);
 }
 
+bool launch_ipa_bias_hx(genie_ctx* h, hipStream_t st);
 void launch_ipa_bias(genie_ctx* h, hipStream_t st) {
     ProfScope ps(h, st, KC_IPA_BIAS);
+    if (launch_ipa_bias_hx(h, st)) return;
     const int N = h->N, ntile = (N + 127) / 128;
     const int LH = h->d.n_structure_layer * h->d.n_head_ipa;
     const size_t lds = 128 * LDZ * sizeof(float);
