@@ -756,6 +756,159 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_out_hx(
     }
 }
 
+// The same kernel with all four weight stages resident in LDS (128 KiB: no weight stream, no barrier inside the tile loop --
+// the eight waves of a work-group run their tiles independently) and the z rows loaded straight into operand registers
+// (no LDS left for the row-tile loader).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_out_hx_r(
+    float* __restrict__ z, const float* __restrict__ xcm, const unsigned char* __restrict__ wimg,
+    const float* __restrict__ bgs, const float* __restrict__ bzs, int N, int NP, int n_wtiles, unsigned cm_bytes,
+    unsigned z_bytes, float sx, float cg, float cz, int rev) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
+    const int lane = threadIdx.x & 63, wave = UNI(threadIdx.x >> 6);
+    const int h = lane >> 5, pl = lane & 31;
+    const int ntile = (N + 31) >> 5;
+    const int n_tiles = (n_wtiles + NW - 1) / NW;
+    const rsrc_t rw = hx_rsrc(wimg, 4 * HX_STAGE_BYTES);
+    const rsrc_t rx = hx_rsrc(xcm, cm_bytes), rz = hx_rsrc(z, z_bytes);
+    const int lane16 = lane * 16;
+    constexpr int PW = 32 / NW;
+    auto issue = [&](int s, int buf) {
+#pragma unroll
+        for (int q = 0; q < PW; ++q) {
+            const int p = PW * wave + q;
+            hx_dma(rw, smb + buf * HX_STAGE_BYTES + p * 1024, lane16, s * HX_STAGE_BYTES + p * 1024);
+        }
+    };
+    int tile = blockIdx.x;
+    issue(0, 0); issue(1, 1); issue(2, 2); issue(3, 3);      // all four weight stages stay in LDS (128 KiB) for every tile
+    hx_stage_landed();
+    __syncthreads();
+#pragma unroll 1
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int wt_raw = HX_PHYS(tile) * NW + wave;
+        const bool act = wt_raw < n_wtiles;
+        const int wt = act ? wt_raw : n_wtiles - 1;
+        const int st = wt % ntile, i = (wt / ntile) % N, b = wt / (ntile * N);
+        const int t0 = st * 32;
+        const int nvalid = act ? min(32, N - t0) : 0;
+        const int prow0 = (b * N + i) * N + t0;                  // first pair row of the tile
+        h8 zh[8], zl[8], xh[8], xl[8];
+        {   // x_cm[((b*128 + c)*NP + i)*NP + t0 + pl], c = 16kc + 8h + e   (t0 + pl < NP always); the z rows come through the
+            // coalesced LDS loader (two halves), the second half's latency is spent on LayerNorm + split of x
+            float4 raw[16], rawz[16];
+            const int cs = NP * NP * 4;
+            const int vx = (8 * h * NP * NP + pl) * 4;
+            const int sxo = ((b * 128 * NP + i) * NP + t0) * 4;
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                raw[2 * kc].x = hx_load(rx, vx, sxo + (16 * kc + 0) * cs); raw[2 * kc].y = hx_load(rx, vx, sxo + (16 * kc + 1) * cs);
+                raw[2 * kc].z = hx_load(rx, vx, sxo + (16 * kc + 2) * cs); raw[2 * kc].w = hx_load(rx, vx, sxo + (16 * kc + 3) * cs);
+                raw[2 * kc + 1].x = hx_load(rx, vx, sxo + (16 * kc + 4) * cs); raw[2 * kc + 1].y = hx_load(rx, vx, sxo + (16 * kc + 5) * cs);
+                raw[2 * kc + 1].z = hx_load(rx, vx, sxo + (16 * kc + 6) * cs); raw[2 * kc + 1].w = hx_load(rx, vx, sxo + (16 * kc + 7) * cs);
+            }
+            {   // this lane's pair row, channels 16 kc + 8 h .. + 7 (rows past the tile: clamped)
+                const float* zrow = z + ((size_t)(prow0 + min(pl, min(32, N - t0) - 1))) * 128 + 8 * h;
+#pragma unroll
+                for (int kc = 0; kc < 8; ++kc) {
+                    rawz[2 * kc] = *reinterpret_cast<const float4*>(zrow + 16 * kc);
+                    rawz[2 * kc + 1] = *reinterpret_cast<const float4*>(zrow + 16 * kc + 4);
+                }
+            }
+            hx_norm_split(xh, xl, raw, sx);
+            hx_norm_split(zh, zl, rawz, sx);
+        }
+        const int voff = (4 * h * 128 + pl) * 4;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x16 ga, gb;
+            {   // gate: A = zn fragments (i = pair), B = W_g (j = channel)
+                const unsigned char* stage = smb + (2 * half) * HX_STAGE_BYTES;
+                float c0 = bgs[(2 * half) * 32 + pl], c1 = bgs[(2 * half + 1) * 32 + pl];
+                asm volatile("" : "+v"(c0), "+v"(c1));      // keep hipcc from hoisting (and spilling) the 16-register splats
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { ga[r] = c0; gb[r] = c1; }
+                h8 f0 = hx_frag(stage, 0, 0, lane), f0l = hx_frag(stage, 0, 1, lane), f1 = hx_frag(stage, 8, 0, lane),
+                   f1l = hx_frag(stage, 8, 1, lane);
+#pragma unroll
+                for (int kc = 0; kc < 8; ++kc) {
+                    const int kn = min(kc + 1, 7);
+                    const h8 n0 = hx_frag(stage, kn, 0, lane), n0l = hx_frag(stage, kn, 1, lane), n1 = hx_frag(stage, 8 + kn, 0, lane),
+                             n1l = hx_frag(stage, 8 + kn, 1, lane);
+                    PIPE_FENCE();
+                    MFH3(zh[kc], zl[kc], f0, f0l, ga);
+                    MFH3(zh[kc], zl[kc], f1, f1l, gb);
+                    PIPE_FENCE();
+                    f0 = n0; f0l = n0l; f1 = n1; f1l = n1l;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    ga[r] = cz * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ga[r] * cg));
+                    gb[r] = cz * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gb[r] * cg));
+                }
+            }
+            {   // update of channel blocks 2 half, 2 half + 1
+                const unsigned char* stage = smb + (2 * half + 1) * HX_STAGE_BYTES;
+                const int ob = 2 * half;
+                f32x16 a0, a1;
+                float c0 = bzs[ob * 32 + pl], c1 = bzs[(ob + 1) * 32 + pl];
+                asm volatile("" : "+v"(c0), "+v"(c1));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { a0[r] = c0; a1[r] = c1; }
+                const int h4 = 4 * h;
+                float zp0[16], zp1[16];
+                if (half == 1) {    // zh / zl are dead after the second gate: the residual rows of this half are requested before its GEMM
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rc = (r & 3) + 8 * (r >> 2);
+                        const int so = (prow0 + rc) * 512 + ob * 128;
+                        const int vr = (h4 < nvalid - rc) ? voff : 0x7FFFFFF0;
+                        zp0[r] = hx_load(rz, vr, so);
+                        zp1[r] = hx_load(rz, vr, so + 128);
+                    }
+                }
+                h8 f0 = hx_frag(stage, 0, 0, lane), f0l = hx_frag(stage, 0, 1, lane), f1 = hx_frag(stage, 8, 0, lane),
+                   f1l = hx_frag(stage, 8, 1, lane);
+#pragma unroll
+                for (int kc = 0; kc < 8; ++kc) {
+                    const int kn = min(kc + 1, 7);
+                    const h8 n0 = hx_frag(stage, kn, 0, lane), n0l = hx_frag(stage, kn, 1, lane), n1 = hx_frag(stage, 8 + kn, 0, lane),
+                             n1l = hx_frag(stage, 8 + kn, 1, lane);
+                    PIPE_FENCE();
+                    MFH3(xh[kc], xl[kc], f0, f0l, a0);
+                    MFH3(xh[kc], xl[kc], f1, f1l, a1);
+                    PIPE_FENCE();
+                    f0 = n0; f0l = n0l; f1 = n1; f1l = n1l;
+                }
+                // residual + store, 8 rows (16 loads) in flight at a time; rows past the tile's valid pairs belong to
+                // the next line: their offset is pushed out of the buffer (load gives 0, store is dropped)
+#pragma unroll
+                for (int r0 = 0; r0 < 16; r0 += 8) {
+                    float zr0[8], zr1[8];
+                    int vo[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int rc = ((r0 + q) & 3) + 8 * ((r0 + q) >> 2);
+                        const int so = (prow0 + rc) * 512 + ob * 128;
+                        vo[q] = (h4 < nvalid - rc) ? voff : 0x7FFFFFF0;
+                        if (half == 1) { zr0[q] = zp0[r0 + q]; zr1[q] = zp1[r0 + q]; }
+                        else { zr0[q] = hx_load(rz, vo[q], so); zr1[q] = hx_load(rz, vo[q], so + 128); }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int rc = ((r0 + q) & 3) + 8 * ((r0 + q) >> 2);
+                        const int so = (prow0 + rc) * 512 + ob * 128;
+                        const float u0 = a0[r0 + q], u1 = a1[r0 + q], g0 = ga[r0 + q], g1 = gb[r0 + q];
+                        hx_store(rz, fmaf(u0, g0, zr0[q]), vo[q], so);
+                        hx_store(rz, fmaf(u1, g1, zr1[q]), vo[q], so + 128);
+                    }
+                    PIPE_FENCE();
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 static int g_hx_cu = 0;
 static int hx_num_cu() {
@@ -827,6 +980,11 @@ static void trimul_slice(genie_ctx* h, HxSlice& v, const TriMulW& w, bool outgoi
     }
     {
         ProfScope ps(h, st, KC_TRIMUL_OUT, v.prof);
+        static const bool resident = getenv("GENIE_OUT_STREAMED") == nullptr;     // default: weights resident in LDS (0.233 vs 0.240 ms per launch)
+        if (resident)
+            hipLaunchKernelGGL(k_trimul_out_hx_r<8>, dim3(hx_grid((n_wt + 7) / 8, 8, v.cus)), dim3(512), 4 * HX_STAGE_BYTES, st, zs, xcm,
+                               x.img_out, x.bgs, x.bzs, N, NP, n_wt, cm_bytes, z_bytes, x.sx, x.cgo, x.cz, (int)(v.launches++ & 1));
+        else
         hipLaunchKernelGGL(k_trimul_out_hx<8>, dim3(hx_grid((n_wt + 7) / 8, 8, v.cus)), dim3(512), HX_LDS_BYTES, st, zs, xcm, x.img_out,
                            x.bgs, x.bzs, N, NP, n_wt, cm_bytes, z_bytes, x.sx, x.cgo, x.cz, (int)(v.launches++ & 1));
     }
@@ -958,7 +1116,7 @@ bool launch_ipa_bias_hx(genie_ctx* h, hipStream_t st) {
 void pair_hx_kernels_init() {
 #define HX_ATTR(k) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, HX_LDS_BYTES)
     HX_ATTR((k_trimul_proj_hx<true, 8>)); HX_ATTR((k_trimul_proj_hx<false, 8>));
-    HX_ATTR(k_trimul_out_hx<8>);
+    HX_ATTR(k_trimul_out_hx<8>); HX_ATTR(k_trimul_out_hx_r<8>);
 #undef HX_ATTR
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_transition_hx<8>), hipFuncAttributeMaxDynamicSharedMemorySize, HX_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_bias_hx), hipFuncAttributeMaxDynamicSharedMemorySize, IB_UNITS * 2048 + 96 * 4);
