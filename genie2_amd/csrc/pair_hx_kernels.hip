@@ -909,6 +909,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_trimul_out_hx_r(
     }
 }
 
+// (Tried: the output kernel transposed, D[channel][pair] with A = weights, so that a lane holds its pair row on both sides of
+//  the GEMMs -- four v_permlane32_swap per k-chunk turn the loaded z row into the accumulator's row set, which is then both the
+//  residual and, with the gate weights packed in that k order, the gate's B operand; LayerNorm applied while splitting, twice
+//  per operand, to stay inside 256 registers; one float4 store per lane and 4-channel group.  Parity green, no second read of
+//  z (-268 MB of L2 reads per launch), but 0.254 ms against 0.237: the doubled split work and the row-per-lane 16-B stores
+//  cost more than the re-read.  tools/probe/swap_probe.hip is the check of the swap's semantics.)
 // ---------------------------------------------------------------------------------------------
 static int g_hx_cu = 0;
 static int hx_num_cu() {
