@@ -1138,7 +1138,7 @@ __global__ void k_scale_copy(const float* __restrict__ in, float* __restrict__ o
 // loads e = 0..7 is exactly the B fragment of the block holding channels {4m + r}, so the stream needs no LDS and no
 // shuffles, and the accumulators of the four blocks form the float4 a lane stores.  No cross-wave reduction, no barrier.
 template <int H, int C, int PQ, int PV, int Q, int MF>
-__global__ __launch_bounds__(MF ? 128 * Q : 512) void k_ipa_attn_q(const float* __restrict__ proj, int ldp, const float* __restrict__ kT,
+__global__ __launch_bounds__(MF ? 128 * Q : 512, MF ? 4 : 1) void k_ipa_attn_q(const float* __restrict__ proj, int ldp, const float* __restrict__ kT,
                                                     const float* __restrict__ v, const float* __restrict__ qp,
                                                     const float* __restrict__ kpT, const float* __restrict__ vp,
                                                     const float* __restrict__ bias, const float* __restrict__ z,
@@ -1282,7 +1282,23 @@ __global__ __launch_bounds__(MF ? 128 * Q : 512) void k_ipa_attn_q(const float* 
         float acc[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) acc[q] = 0.f;
-        for (int j0 = jb; j0 < je; j0 += 8) {
+        // 16 rows of V in flight per thread (the loop is a chain of L2 round trips), then 8 at a time for the tail
+        int j0 = jb;
+        for (; j0 + 16 <= je; j0 += 16) {
+            float x[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) x[k] = vv[(size_t)min(j0 + k, N - 1) * ld];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const float* ar = att + (q * H + hh) * NP8 + j0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 a = *reinterpret_cast<const float4*>(ar + 4 * u);
+                    acc[q] += a.x * x[4 * u]; acc[q] += a.y * x[4 * u + 1]; acc[q] += a.z * x[4 * u + 2]; acc[q] += a.w * x[4 * u + 3];
+                }
+            }
+        }
+        for (; j0 < je; j0 += 8) {
             float x[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) x[k] = vv[(size_t)min(j0 + k, N - 1) * ld];
