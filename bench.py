@@ -147,6 +147,11 @@ def main():
     dist = world > 1 or os.environ.get('GENIE_BENCH_FORCE_DIST') == '1'     # (single-rank rehearsal of the RCCL path)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    # stdout carries exactly ONE line, the JSON: RCCL prints its version banner to stdout when the communicator is created, so
+    # file descriptor 1 points at stderr until that line is written
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     if dist:
         import torch.distributed as td
         td.init_process_group('nccl', device_id=dev)
@@ -248,7 +253,10 @@ def main():
             out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']
         else:
             out['cpu_baseline'] = None
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist:
         td.barrier()
         td.destroy_process_group()
