@@ -636,6 +636,27 @@ int genie_frenet(genie_handle_t h, genie_stream_t stream, const float* trans, fl
     return GENIE_OK;
 }
 
+int genie_q_sample(genie_handle_t h, genie_stream_t stream, const float* x0, const float* z, const float* c_x0, const float* c_z,
+                   float* trans_out, float* rots_out) {
+    if (!h || !h->have_feats) { if (h) SET_ERR(h, "genie_q_sample: no batch bound"); return h ? GENIE_E_STATE : GENIE_E_ARG; }
+    if (!x0 || !z || !c_x0 || !c_z || !trans_out || !rots_out) { SET_ERR(h, "genie_q_sample: null tensor"); return GENIE_E_ARG; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    launch_q_sample(h, (hipStream_t)stream, x0, z, c_x0, c_z, trans_out);
+    launch_frenet(h, (hipStream_t)stream, 0, 0, 0.f, trans_out, rots_out, nullptr, nullptr);
+    HIP_TRY(h, hipGetLastError());
+    return GENIE_OK;
+}
+
+int genie_training_loss(genie_handle_t h, genie_stream_t stream, const float* z_pred, const float* z, float condition_loss_weight,
+                        float* losses_out, float* grad_out) {
+    if (!h || !h->have_feats) { if (h) SET_ERR(h, "genie_training_loss: no batch bound"); return h ? GENIE_E_STATE : GENIE_E_ARG; }
+    if (!z_pred || !z || !losses_out) { SET_ERR(h, "genie_training_loss: null tensor"); return GENIE_E_ARG; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    launch_training_loss(h, (hipStream_t)stream, z_pred, z, condition_loss_weight, losses_out, grad_out);
+    HIP_TRY(h, hipGetLastError());
+    return GENIE_OK;
+}
+
 int genie_p_sample(genie_handle_t h, genie_stream_t stream, int step, float scale, float* trans_inout, float* rots_out,
                    const float* z, const float* eps) {
     if (int rc = check_ready(h, "genie_p_sample")) return rc;

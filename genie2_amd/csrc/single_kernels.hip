@@ -1460,6 +1460,65 @@ __global__ __launch_bounds__(MF ? 128 * Q : 512, MF ? 4 : 1) void k_ipa_attn_q(c
 }
 
 // ---------------------------------------------------------------------------
+// Training step, the two ends around the denoiser (diffusion/genie.py:77-105, utils/loss.py:4-36)
+// ---------------------------------------------------------------------------
+__global__ void k_q_sample(const float* __restrict__ x0, const float* __restrict__ z, const float* __restrict__ c0,
+                           const float* __restrict__ c1, float* __restrict__ out, int n_per_b, int total) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < total) { const int b = u / n_per_b; out[u] = c0[b] * x0[u] + c1[b] * z[u]; }
+}
+
+// one work-group per structure: masked sums of err = sqrt(eps + |z_pred - z|^2) over the conditioned / infilled residues,
+// and d weighted_loss / d z_pred = (w m_c + m_i) (z_pred - z) / err / (B (w n_c + n_i))
+__global__ __launch_bounds__(256) void k_training_loss(const float* __restrict__ zp, const float* __restrict__ z,
+                                                       const int32_t* __restrict__ rmask, const uint8_t* __restrict__ fsm, int B, int N,
+                                                       float w, float* __restrict__ losses, float* __restrict__ stats, float* __restrict__ grad) {
+    __shared__ float red[4][4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};                    // condition loss, infill loss, n condition, n infill
+    for (int n = tid; n < N; n += 256) {
+        const size_t o = ((size_t)b * N + n) * 3;
+        const float dx = zp[o] - z[o], dy = zp[o + 1] - z[o + 1], dz = zp[o + 2] - z[o + 2];
+        const float err = sqrtf(1e-10f + ((dx * dx + dy * dy) + dz * dz));
+        const float m = (float)rmask[b * N + n], f = fsm[b * N + n] ? 1.f : 0.f;
+        const float mc = m * f, mi = m * (1.f - f);
+        v[0] += err * mc; v[1] += err * mi; v[2] += mc; v[3] += mi;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+        if (lane == 0) red[wave][k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    if (tid == 0) {
+        losses[2 + b] = v[0]; losses[2 + B + b] = v[1];
+        stats[2 * b] = (v[0] + v[1]) / (v[2] + v[3]);                        // unweighted_losses[b] (num_residues = mask sum)
+        stats[2 * b + 1] = (w * v[0] + v[1]) / (w * v[2] + v[3]);            // weighted_losses[b]
+    }
+    if (grad) {
+        const float coef = 1.0f / ((float)B * (w * v[2] + v[3]));
+        for (int n = tid; n < N; n += 256) {
+            const size_t o = ((size_t)b * N + n) * 3;
+            const float dx = zp[o] - z[o], dy = zp[o + 1] - z[o + 1], dz = zp[o + 2] - z[o + 2];
+            const float err = sqrtf(1e-10f + ((dx * dx + dy * dy) + dz * dz));
+            const float m = (float)rmask[b * N + n], f = fsm[b * N + n] ? 1.f : 0.f;
+            const float g = coef * (w * m * f + m * (1.f - f)) / err;
+            grad[o] = g * dx; grad[o + 1] = g * dy; grad[o + 2] = g * dz;
+        }
+    }
+}
+__global__ void k_training_loss_mean(const float* __restrict__ stats, int B, float* __restrict__ losses) {
+    if (threadIdx.x == 0) {
+        float u = 0.f, wl = 0.f;
+        for (int b = 0; b < B; ++b) { u += stats[2 * b]; wl += stats[2 * b + 1]; }
+        losses[0] = u / (float)B; losses[1] = wl / (float)B;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 void launch_single_input(genie_ctx* h, hipStream_t st, const int32_t* timesteps) {
@@ -1608,6 +1667,18 @@ bool launch_struct_tail(genie_ctx* h, hipStream_t st, const StructLayerW& S, con
                 v[2] - v[1], v[3] - v[2], v[4] - v[3], v[5] - v[4], v[6] - v[5], v[7] - v[6], v[7] - v[0]);
     }
     return true;
+}
+
+void launch_q_sample(genie_ctx* h, hipStream_t st, const float* x0, const float* z, const float* c0, const float* c1, float* trans_out) {
+    ProfScope ps(h, st, KC_MISC);
+    const int total = h->B * h->N * 3;
+    hipLaunchKernelGGL(k_q_sample, dim3((total + 255) / 256), dim3(256), 0, st, x0, z, c0, c1, trans_out, h->N * 3, total);
+}
+void launch_training_loss(genie_ctx* h, hipStream_t st, const float* zp, const float* z, float w, float* losses, float* grad) {
+    ProfScope ps(h, st, KC_MISC);
+    float* stats = h->loop_z;                       // [B,N,3] scratch of the reverse loop: 2 B floats are used
+    hipLaunchKernelGGL(k_training_loss, dim3(h->B), dim3(256), 0, st, zp, z, h->f_rmask, h->f_fsm, h->B, h->N, w, losses, stats, grad);
+    hipLaunchKernelGGL(k_training_loss_mean, dim3(1), dim3(64), 0, st, stats, h->B, losses);
 }
 
 void launch_frenet(genie_ctx* h, hipStream_t st, int mode, int step, float scale, float* trans, float* rots, const float* z,

@@ -96,6 +96,29 @@ class GenieEngine:
         capi.check(self._h, self.lib.genie_frenet(self._h, self._stream(), _ptr(trans), _ptr(rots)), 'genie_frenet')
         return rots
 
+    def q_sample(self, x0, z, c_x0, c_z):
+        """genie.py:80-87 for the bound batch: (trans_s, rots_s) from x0, masked noise z and the two schedule terms [B]."""
+        x0, z = self._dev(x0, torch.float32), self._dev(z, torch.float32)
+        c0, c1 = self._dev(c_x0, torch.float32), self._dev(c_z, torch.float32)
+        trans = torch.empty(self.B, self.N, 3, device=self.device)
+        rots = torch.empty(self.B, self.N, 3, 3, device=self.device)
+        rc = self.lib.genie_q_sample(self._h, self._stream(), _ptr(x0), _ptr(z), _ptr(c0), _ptr(c1), _ptr(trans), _ptr(rots))
+        capi.check(self._h, rc, 'genie_q_sample')
+        return trans, rots
+
+    def training_loss(self, z_pred, z, condition_loss_weight, grad=True):
+        """genie.py:90-105: dict(unweighted_loss, weighted_loss, condition_losses, infill_losses[, grad = d weighted / d z_pred])."""
+        zp, z = self._dev(z_pred, torch.float32), self._dev(z, torch.float32)
+        B = self.B
+        out = torch.empty(2 + 2 * B, device=self.device)
+        g = torch.empty(B, self.N, 3, device=self.device) if grad else None
+        rc = self.lib.genie_training_loss(self._h, self._stream(), _ptr(zp), _ptr(z), float(condition_loss_weight), _ptr(out), _ptr(g))
+        capi.check(self._h, rc, 'genie_training_loss')
+        res = {'unweighted_loss': out[0], 'weighted_loss': out[1], 'condition_losses': out[2:2 + B], 'infill_losses': out[2 + B:]}
+        if grad:
+            res['grad'] = g
+        return res
+
     def denoise(self, trans, rots, timesteps, quat_codes=None, taps=()):
         """Denoiser.forward.  Returns {'z': ..., <tap>: ...}."""
         B, N = self.B, self.N

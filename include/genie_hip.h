@@ -167,6 +167,26 @@ int genie_sample_loop(genie_handle_t h, genie_stream_t stream, float scale,
 int genie_set_math(genie_handle_t h, int mode);
 int genie_get_math(genie_handle_t h);
 
+/* ---- training step: the two ends around the denoiser -------------------
+ * First pieces of the training row (genie/diffusion/genie.py:66-105); the backward pass through the
+ * denoiser is not built yet.  Both work on the batch bound with genie_prepare_features. */
+
+/* Forward noising + frames (genie.py:80-87):
+ *   trans_s = c_x0[b] x0 + c_z[b] z,   rots_s = compute_frenet_frames(trans_s)
+ * with c_x0 = sqrt_alphas_cumprod[s], c_z = sqrt_one_minus_alphas_cumprod[s] (device, [B]; ddpm.py:54-56) and z
+ * already masked by the caller (genie.py:77). */
+int genie_q_sample(genie_handle_t h, genie_stream_t stream, const float* x0 /*[B,N,3]*/, const float* z /*[B,N,3]*/,
+                   const float* c_x0 /*[B]*/, const float* c_z /*[B]*/, float* trans_out /*[B,N,3]*/,
+                   float* rots_out /*[B,N,3,3]*/);
+
+/* The loss training_step returns (genie.py:90-105, utils/loss.py:4-36) and its gradient:
+ *   losses_out (device) [2 + 2B] = unweighted_loss, weighted_loss, condition_losses[B], infill_losses[B];
+ *   grad_out [B,N,3] = d weighted_loss / d z_pred, or NULL.
+ * Masks are the bound batch's residue_mask and fixed_sequence_mask; num_residues is taken as the mask's
+ * row sum (feat_utils.py:17-65 builds them so). */
+int genie_training_loss(genie_handle_t h, genie_stream_t stream, const float* z_pred /*[B,N,3]*/, const float* z /*[B,N,3]*/,
+                        float condition_loss_weight, float* losses_out, float* grad_out);
+
 /* ---- measurement ------------------------------------------------------- */
 
 /* Per-kernel-class HIP-event timing on the launch stream (bench.py roofline

@@ -517,6 +517,50 @@ def denoiser_forward(sd, dims, rots, trans, timesteps, features, quat_mode='eigh
     return dict(z=trans0 - t_out, s=s, p=p, s_final=s_fin, rots=r_out, trans=t_out)
 
 
+# --------------------------------------------------------------------------
+# training step, the two ends around the denoiser (genie/diffusion/genie.py:66-105, utils/loss.py:4-36)
+# --------------------------------------------------------------------------
+
+def training_schedule(n_timestep):
+    """ddpm.py:40-57: the two terms training_step indexes (genie.py:80-81)."""
+    ac = setup_schedule(n_timestep)['alphas_cumprod']
+    return dict(sqrt_alphas_cumprod=torch.sqrt(ac), sqrt_one_minus_alphas_cumprod=torch.sqrt(1. - ac))
+
+
+def q_sample(x0, s, z, chains, mask, sched):
+    """genie.py:77-87: noised coordinates and their Frenet frames.  z is already masked (genie.py:77)."""
+    trans = sched['sqrt_alphas_cumprod'][s.long()].view(-1, 1, 1) * x0 + \
+        sched['sqrt_one_minus_alphas_cumprod'][s.long()].view(-1, 1, 1) * z
+    return trans, compute_frenet_frames(trans, chains, mask)
+
+
+def mse(x_pred, x, mask, aggregate=None, eps=1e-10):
+    """utils/loss.py:4-36 (a masked per-residue L2 error despite the name)."""
+    errors = (eps + torch.sum((x_pred - x) ** 2, dim=-1)) ** 0.5
+    if aggregate is None:
+        return errors * mask
+    if aggregate == 'mean':
+        return torch.sum(errors * mask, dim=-1) / torch.sum(mask, dim=-1)
+    assert aggregate == 'sum'
+    return torch.sum(errors * mask, dim=-1)
+
+
+def training_loss(z_pred, z, features, condition_loss_weight):
+    """genie.py:90-105.  Returns dict(unweighted_loss, weighted_loss (what training_step returns), and the
+    per-structure condition / infill sums)."""
+    rm = features['residue_mask'].float()
+    fs = features['fixed_sequence_mask'].bool()
+    condition_mask = rm * fs
+    infill_mask = rm * ~fs
+    cond = mse(z_pred, z, condition_mask, aggregate='sum')
+    infill = mse(z_pred, z, infill_mask, aggregate='sum')
+    unweighted = (cond + infill) / features['num_residues'].reshape(-1).float()
+    w = condition_loss_weight
+    weighted = (w * cond + infill) / (w * torch.sum(condition_mask, dim=-1) + torch.sum(infill_mask, dim=-1))
+    return dict(unweighted_loss=torch.mean(unweighted), weighted_loss=torch.mean(weighted), condition_losses=cond,
+                infill_losses=infill)
+
+
 def prepare_features(features):
     """Same dtypes the model sees after feat_utils.py:304-321."""
     out = dict(features)

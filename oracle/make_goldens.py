@@ -43,6 +43,7 @@ from genie.model.model import Denoiser  # noqa: E402
 from genie.diffusion.schedule import get_betas  # noqa: E402
 from genie.utils.affine_utils import T, quat_to_rot, rot_to_quat  # noqa: E402
 from genie.utils.geo_utils import compute_frenet_frames  # noqa: E402
+from genie.utils.loss import mse as ref_mse  # noqa: E402
 from genie.utils.encoding import sinusoidal_encoding  # noqa: E402
 from genie.utils import feat_utils  # noqa: E402
 from genie.sampler.unconditional import UnconditionalSampler  # noqa: E402
@@ -404,6 +405,54 @@ def gen_motif(sd):
          scale=scale, seed=seed, **feats_to_np(feats))
 
 
+def gen_train():
+    """The two ends of Genie.training_step (diffusion/genie.py:66-105) around the denoiser call, driven line by line with
+    the reference's own get_betas / compute_frenet_frames / mse (the LightningModule itself is not importable here):
+    forward noising + frames, and the loss with its gradient with respect to the predicted noise (reference autograd)."""
+    g = torch.Generator().manual_seed(77)
+    T_ = 1000
+    betas = get_betas(T_, 'cosine')
+    ac = torch.cumprod(1. - betas, 0)                                # ddpm.py:45-46
+    sqrt_ac, sqrt_1mac = torch.sqrt(ac), torch.sqrt(1. - ac)         # ddpm.py:54,56
+    # (batch of 4, not 3: the reference's torch.cross without dim= picks the batch axis when B == 3, SURVEY section 7)
+    f = O.empty_features([24, 17, 9, 20], chains_per_sample=[[10, 14], [17], [4, 5], [20]])
+    B, N = f['residue_mask'].shape
+    f['fixed_sequence_mask'][0, 3:9] = True                         # a motif-conditioned structure, an unconditional one, ...
+    f['fixed_sequence_mask'][2, 0:4] = True
+    f['atom_positions'] = torch.randn(B, N, 3, generator=g) * 8 * f['residue_mask'].unsqueeze(-1)
+    s = torch.tensor([1, 500, 1000, 37])
+    z = torch.randn(B, N, 3, generator=g) * f['residue_mask'].unsqueeze(-1)                                     # genie.py:77
+    trans_s = sqrt_ac[s].view(-1, 1, 1) * f['atom_positions'] + sqrt_1mac[s].view(-1, 1, 1) * z                 # genie.py:80-81
+    rots_s = compute_frenet_frames(trans_s, f['chain_index'], f['residue_mask'])                                # genie.py:82-86
+    z_pred = (z + 0.3 * torch.randn(B, N, 3, generator=g)).requires_grad_(True)     # stands in for output['z']
+    w = 2.5                                                          # config.training['condition_loss_weight'] in the test
+    rm, fs = f['residue_mask'], f['fixed_sequence_mask']
+    condition_mask = rm * fs                                         # genie.py:91-92
+    infill_mask = rm * ~fs
+    condition_losses = ref_mse(z_pred, z, condition_mask, aggregate='sum')
+    infill_losses = ref_mse(z_pred, z, infill_mask, aggregate='sum')
+    unweighted_losses = (condition_losses + infill_losses) / f['num_residues']
+    weighted_losses = (w * condition_losses + infill_losses) / (w * torch.sum(condition_mask, dim=-1) + torch.sum(infill_mask, dim=-1))
+    unweighted_loss, weighted_loss = torch.mean(unweighted_losses), torch.mean(weighted_losses)
+    weighted_loss.backward()
+    # the restatement agrees with the reference
+    sched = O.training_schedule(T_)
+    assert maxdiff(sched['sqrt_alphas_cumprod'], sqrt_ac) == 0 and maxdiff(sched['sqrt_one_minus_alphas_cumprod'], sqrt_1mac) == 0
+    tr_o, ro_o = O.q_sample(f['atom_positions'], s, z, f['chain_index'], f['residue_mask'], sched)
+    assert maxdiff(tr_o, trans_s) == 0 and maxdiff(ro_o, rots_s) < 1e-6
+    zp = z_pred.detach().clone().requires_grad_(True)
+    lo = O.training_loss(zp, z, f, w)
+    lo['weighted_loss'].backward()
+    assert maxdiff(lo['weighted_loss'].detach(), weighted_loss.detach()) < 1e-7 and maxdiff(zp.grad, z_pred.grad) < 1e-8
+    assert maxdiff(lo['unweighted_loss'].detach(), unweighted_loss.detach()) < 1e-7
+    save('train_ends_n24_b4', atom_positions=f['atom_positions'], residue_mask=f['residue_mask'], chain_index=f['chain_index'],
+         residue_index=f['residue_index'], fixed_sequence_mask=f['fixed_sequence_mask'], num_residues=f['num_residues'],
+         lengths=np.array([24, 17, 9, 20]), s=s, z=z, sqrt_alphas_cumprod_s=sqrt_ac[s], sqrt_one_minus_alphas_cumprod_s=sqrt_1mac[s],
+         trans_s=trans_s, rots_s=rots_s, z_pred=z_pred.detach(), condition_loss_weight=np.float32(w),
+         condition_losses=condition_losses.detach(), infill_losses=infill_losses.detach(),
+         unweighted_loss=unweighted_loss.detach(), weighted_loss=weighted_loss.detach(), grad_z_pred=z_pred.grad)
+
+
 def main():
     torch.manual_seed(0)
     print('weights (synthetic recipe, seed 0)')
@@ -422,6 +471,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'motif':
         print('motif'); gen_motif(sd)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'train':
+        print('train'); gen_train()
+        return
     print('schedule'); gen_schedule()
     print('encoding'); gen_encoding()
     print('geometry'); gen_geometry()
@@ -429,6 +481,7 @@ def main():
     gen_single_calls(sd)
     print('trajectory'); gen_trajectory(sd)
     print('motif'); gen_motif(sd)
+    print('train'); gen_train()
 
 
 if __name__ == '__main__':

@@ -380,3 +380,25 @@ def test_fused_structure_tail_matches_separate_launches(base_engine, monkeypatch
         assert torch.isfinite(a).all()
         assert mdiff(a, b) <= 4e-6 * max(1.0, float(b.abs().max())), k
         assert mdiff(z8[k].cpu()[m], a) <= 4e-6 * max(1.0, float(b.abs().max())), k
+
+
+def test_training_step_ends_match_reference_golden(base_engine):
+    """genie_q_sample / genie_training_loss (diffusion/genie.py:77-105) against the reference's own results
+    (tests/golden/train_ends_n24_b4.npz: its get_betas, compute_frenet_frames, mse and autograd)."""
+    g = load_golden('train_ends_n24_b4')
+    f = O.empty_features([int(x) for x in g['lengths']])
+    for k in ('residue_mask', 'chain_index', 'residue_index', 'fixed_sequence_mask', 'num_residues'):
+        f[k] = t(g[k])
+    base_engine.bind_features(f)
+    tr, ro = base_engine.q_sample(t(g['atom_positions']), t(g['z']), t(g['sqrt_alphas_cumprod_s']), t(g['sqrt_one_minus_alphas_cumprod_s']))
+    assert mdiff(tr, t(g['trans_s'])) <= 2e-6 * float(np.abs(g['trans_s']).max())
+    assert mdiff(ro, t(g['rots_s'])) < 2e-6
+    out = base_engine.training_loss(t(g['z_pred']), t(g['z']), float(g['condition_loss_weight']))
+    assert abs(float(out['weighted_loss']) - float(g['weighted_loss'])) <= 2e-6 * float(g['weighted_loss'])
+    assert abs(float(out['unweighted_loss']) - float(g['unweighted_loss'])) <= 2e-6 * float(g['unweighted_loss'])
+    assert mdiff(out['condition_losses'], t(g['condition_losses'])) <= 1e-5
+    assert mdiff(out['infill_losses'], t(g['infill_losses'])) <= 1e-5
+    assert mdiff(out['grad'], t(g['grad_z_pred'])) <= 2e-6 * float(np.abs(g['grad_z_pred']).max())
+    # no gradient requested: same losses
+    out2 = base_engine.training_loss(t(g['z_pred']), t(g['z']), float(g['condition_loss_weight']), grad=False)
+    assert float(out2['weighted_loss']) == float(out['weighted_loss']) and 'grad' not in out2

@@ -83,3 +83,31 @@ def test_trajectory_matches_reference(base_weights):
     rms = float(ref.pow(2).mean().sqrt())
     assert (final - ref).abs().max() <= 1e-4 * rms
     assert (torch.stack(rec) - t(g['every10'])).abs().max() <= 1e-4 * rms
+
+
+def _train_features(g):
+    f = O.empty_features([int(x) for x in g['lengths']])
+    for k in ('residue_mask', 'chain_index', 'residue_index', 'fixed_sequence_mask', 'num_residues'):
+        f[k] = t(g[k])
+    f['atom_positions'] = t(g['atom_positions'])
+    return f
+
+
+def test_training_step_ends_match_reference_golden():
+    """The two ends of Genie.training_step around the denoiser (diffusion/genie.py:77-105): forward noising + frames and
+    the loss with its gradient, against what the reference's own get_betas / compute_frenet_frames / mse + autograd gave."""
+    g = load_golden('train_ends_n24_b4')
+    f = _train_features(g)
+    sched = O.training_schedule(1000)
+    s = t(g['s'])
+    assert torch.equal(sched['sqrt_alphas_cumprod'][s], t(g['sqrt_alphas_cumprod_s']))
+    assert torch.equal(sched['sqrt_one_minus_alphas_cumprod'][s], t(g['sqrt_one_minus_alphas_cumprod_s']))
+    tr, ro = O.q_sample(f['atom_positions'], s, t(g['z']), f['chain_index'], f['residue_mask'], sched)
+    assert torch.equal(tr, t(g['trans_s'])) and (ro - t(g['rots_s'])).abs().max() < 1e-6
+    zp = t(g['z_pred']).clone().requires_grad_(True)
+    lo = O.training_loss(zp, t(g['z']), f, float(g['condition_loss_weight']))
+    lo['weighted_loss'].backward()
+    assert abs(float(lo['weighted_loss'].detach()) - float(g['weighted_loss'])) < 1e-7
+    assert abs(float(lo['unweighted_loss'].detach()) - float(g['unweighted_loss'])) < 1e-7
+    assert (lo['condition_losses'].detach() - t(g['condition_losses'])).abs().max() < 1e-5
+    assert (zp.grad - t(g['grad_z_pred'])).abs().max() < 1e-8
