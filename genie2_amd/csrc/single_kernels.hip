@@ -1596,7 +1596,7 @@ void launch_ipa_attn(genie_ctx* h, hipStream_t st, int layer, const float* head_
         const dim3 grid(h->B * ((h->N + IPA_Q - 1) / IPA_Q));
         const int rev = (int)((layer ^ h->hx_launches ^ 1) & 1);
         static unsigned long long* ts = nullptr;
-        if (!ts && getenv("GENIE_SR_TS")) hipMalloc((void**)&ts, 64 * sizeof(unsigned long long));
+        if (!ts && getenv("GENIE_SR_TS")) (void)hipMalloc((void**)&ts, 64 * sizeof(unsigned long long));
         if (h->hx && ipa_use_q8(d, h->N))
             hipLaunchKernelGGL((k_ipa_attn_q<12, 16, 4, 8, IPA_Q8, 1>), dim3(h->B * ((h->N + IPA_Q8 - 1) / IPA_Q8)), dim3(1024),
                                ipa_attn_q_lds(d, h->N, true, IPA_Q8), st, h->proj, ldp, h->kT, h->v, h->qp, h->kpT, h->vp, h->ipa_bias, h->p,
@@ -1611,8 +1611,8 @@ void launch_ipa_attn(genie_ctx* h, hipStream_t st, int layer, const float* head_
                                h->B, h->N, layer, rev, h->pmax, ts);
         if (ts) {
             unsigned long long v[24] = {0};
-            hipStreamSynchronize(st);
-            hipMemcpy(v, ts, sizeof(v), hipMemcpyDeviceToHost);
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(v, ts, sizeof(v), hipMemcpyDeviceToHost);
             fprintf(stderr, "ipa_attn wg0 (cycles): q-load %llu logits %llu softmax %llu o/o_pt %llu o_pair %llu total %llu; starts of wg 64k:", v[1] - v[0],
                     v[2] - v[1], v[3] - v[2], v[4] - v[3], v[5] - v[4], v[5] - v[0]);
             for (int k = 0; k < 8; ++k) fprintf(stderr, " %lld", (long long)(v[16 + k] - v[0]));
@@ -1654,15 +1654,15 @@ bool launch_struct_tail(genie_ctx* h, hipStream_t st, const StructLayerW& S, con
     }
     ProfScope ps(h, st, KC_STRUCT_ROWS);
     static unsigned long long* ts = nullptr;
-    if (!ts && getenv("GENIE_SR_TS")) hipMalloc((void**)&ts, 64 * sizeof(unsigned long long));
+    if (!ts && getenv("GENIE_SR_TS")) (void)hipMalloc((void**)&ts, 64 * sizeof(unsigned long long));
     const int nrb = (M + 31) / 32;                 // row work-groups; + 64 L2 prefetchers (8 per XCD) on CUs the rows leave idle
     hipLaunchKernelGGL((k_struct_rows_hx<12>), dim3(nrb + 64), dim3(768), struct_rows_lds(), st, h->spart, SR_KSPLIT, zs, S.out_b, h->s,
                        S.ln_ipa_g, S.ln_ipa_b, w1->img, w1->inv_s, S.t1_b, w2->img, w2->inv_s, S.t2_b, w3->img, w3->inv_s, S.t3_b,
                        S.ln_tr_g, S.ln_tr_b, S.bb_w, S.bb_b, h->s, h->rots_w, h->trans_w, M, trans_in, z_out, 1.0f / h->d.rescale, nrb, ts);
     if (ts) {
         unsigned long long v[8] = {0};
-        hipStreamSynchronize(st);
-        hipMemcpy(v, ts, sizeof(v), hipMemcpyDeviceToHost);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(v, ts, sizeof(v), hipMemcpyDeviceToHost);
         fprintf(stderr, "struct_rows wg0 (100 MHz ticks): load %llu ln %llu lin1 %llu lin2 %llu lin3 %llu ln %llu bb %llu total %llu\n", v[1] - v[0],
                 v[2] - v[1], v[3] - v[2], v[4] - v[3], v[5] - v[4], v[6] - v[5], v[7] - v[6], v[7] - v[0]);
     }
@@ -1708,21 +1708,21 @@ void launch_scale_copy(genie_ctx* h, hipStream_t st, const float* in, float* out
 }
 
 void single_kernels_init(const genie_dims_t& d, int n_max) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_struct_rows_hx<12>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_struct_rows_hx<12>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)struct_rows_lds());
     if (ipa_is_base(d)) {
         if (ipa_use_q(d, n_max)) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn_q<12, 16, 4, 8, IPA_Q, 0>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn_q<12, 16, 4, 8, IPA_Q, 0>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipa_attn_q_lds(d, n_max));
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn_q<12, 16, 4, 8, IPA_Q, 1>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn_q<12, 16, 4, 8, IPA_Q, 1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipa_attn_q_lds(d, n_max, true));
             if (ipa_use_q8(d, n_max))
-                hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn_q<12, 16, 4, 8, IPA_Q8, 1>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn_q<12, 16, 4, 8, IPA_Q8, 1>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipa_attn_q_lds(d, n_max, true, IPA_Q8));
         } else
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn_t<12, 16, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn_t<12, 16, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)ipa_attn_t1_lds(d, n_max));
     } else
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)ipa_attn_lds(d, n_max));
 }

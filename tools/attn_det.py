@@ -1,4 +1,4 @@
-"""Developer aid (GPU box): run-to-run determinism of the denoiser and Q=8 vs Q=4 attention work-groups."""
+"""Developer aid (GPU box): run-to-run determinism of the denoiser and 4-query (default) vs 8-query attention work-groups."""
 import os
 import sys
 import torch
@@ -18,15 +18,15 @@ for lengths in ([45, 23, 38], [256] * 2, [64]):
     r = eng.frenet(x)
     ts = torch.full((B,), 500, dtype=torch.int32)
     out = []
-    for env in ({}, {}, {'GENIE_IPA_Q4': '1'}, {'GENIE_NO_STRUCT_FUSE': '1'}, {'GENIE_IPA_Q4': '1', 'GENIE_NO_STRUCT_FUSE': '1'}):
-        for k in ('GENIE_IPA_Q4', 'GENIE_NO_STRUCT_FUSE'):
+    for env in ({}, {}, {'GENIE_IPA_Q8': '1'}, {'GENIE_NO_STRUCT_FUSE': '1'}, {'GENIE_IPA_Q8': '1', 'GENIE_NO_STRUCT_FUSE': '1'}):
+        for k in ('GENIE_IPA_Q8', 'GENIE_NO_STRUCT_FUSE'):
             os.environ.pop(k, None)
         os.environ.update(env)
         o = eng.denoise(x, r, ts, None, taps=('s_final',))
         out.append({k: v.cpu() for k, v in o.items()})
-    for k in ('GENIE_IPA_Q4', 'GENIE_NO_STRUCT_FUSE'):
+    for k in ('GENIE_IPA_Q8', 'GENIE_NO_STRUCT_FUSE'):
         os.environ.pop(k, None)
-    names = ['same again', 'Q4', 'no fuse', 'Q4 + no fuse']
+    names = ['same again', 'Q8', 'no fuse', 'Q8 + no fuse']
     m = f['residue_mask'].bool()
     for n, o in zip(names, out[1:]):
         print(lengths[:3], n, 'valid residues: z %.3e s_final %.3e; all rows: z %.3e' % (
