@@ -36,12 +36,12 @@ void prof_begin(genie_ctx* h, hipStream_t st, int cls) {
     }
     genie_ctx::ProfRec& r = h->prof_recs[h->prof_n];
     r.cls = cls;
-    hipEventCreate(&r.a);
-    hipEventCreate(&r.b);
-    hipEventRecord(r.a, st);
+    (void)hipEventCreate(&r.a);
+    (void)hipEventCreate(&r.b);
+    (void)hipEventRecord(r.a, st);
 }
 void prof_end(genie_ctx* h, hipStream_t st) {
-    hipEventRecord(h->prof_recs[h->prof_n].b, st);
+    (void)hipEventRecord(h->prof_recs[h->prof_n].b, st);
     h->prof_n++;
 }
 
@@ -108,19 +108,19 @@ int genie_create(const genie_dims_t* dims, int device, genie_handle_t* out) {
 }
 
 static void free_batch(genie_ctx* h) {
-    if (h->ws) { hipFree(h->ws); h->ws = nullptr; h->ws_bytes = 0; }
+    if (h->ws) { (void)hipFree(h->ws); h->ws = nullptr; h->ws_bytes = 0; }
     h->have_feats = false;
 }
 
 void genie_destroy(genie_handle_t h) {
     if (!h) return;
-    hipSetDevice(h->device);
+    (void)hipSetDevice(h->device);
     free_batch(h);
-    if (h->wdev) hipFree(h->wdev);
-    if (h->hxdev) hipFree(h->hxdev);
-    if (h->pos_tab) hipFree(h->pos_tab);
+    if (h->wdev) (void)hipFree(h->wdev);
+    if (h->hxdev) (void)hipFree(h->hxdev);
+    if (h->pos_tab) (void)hipFree(h->pos_tab);
     free(h->sched_host);
-    for (int i = 0; i < h->prof_n; ++i) { hipEventDestroy(h->prof_recs[i].a); hipEventDestroy(h->prof_recs[i].b); }
+    for (int i = 0; i < h->prof_n; ++i) { (void)hipEventDestroy(h->prof_recs[i].a); (void)hipEventDestroy(h->prof_recs[i].b); }
     free(h->prof_recs);
     delete[] h->pair;
     delete[] h->st;
@@ -423,13 +423,13 @@ int genie_load_weights(genie_handle_t h, const float* blob, size_t n_floats) {
     slot(&h->ipa_bias_b, img.raw(bb_all.data(), bb_all.size()));
     if (c.left != 0) { SET_ERR(h, "genie_load_weights: %zu floats left over", c.left); return GENIE_E_ARG; }
 
-    if (h->wdev) { hipFree(h->wdev); h->wdev = nullptr; }
+    if (h->wdev) { (void)hipFree(h->wdev); h->wdev = nullptr; }
     img.add(64);
     HIP_TRY(h, hipMalloc((void**)&h->wdev, img.data.size() * sizeof(float)));
     HIP_TRY(h, hipMemcpy(h->wdev, img.data.data(), img.data.size() * sizeof(float), hipMemcpyHostToDevice));
     h->wdev_floats = img.data.size();
     for (auto& f : fix) *f.first = h->wdev + f.second;
-    if (h->hxdev) { hipFree(h->hxdev); h->hxdev = nullptr; }
+    if (h->hxdev) { (void)hipFree(h->hxdev); h->hxdev = nullptr; }
     hx.begin();
     HIP_TRY(h, hipMalloc((void**)&h->hxdev, hx.d.size() * 2 + 256));
     HIP_TRY(h, hipMemcpy(h->hxdev, hx.d.data(), hx.d.size() * 2, hipMemcpyHostToDevice));
@@ -449,7 +449,7 @@ int genie_set_tables(genie_handle_t h, const float* pos_tab, int n_pos, const fl
     const genie_dims_t& d = h->d;
     const size_t T1 = d.n_timestep + 1;
     const size_t a = (size_t)n_pos * d.c_pos_emb, b = (size_t)n_chain * d.c_chain_emb, c = T1 * d.c_timestep_emb, s = 4 * T1;
-    if (h->pos_tab) hipFree(h->pos_tab);
+    if (h->pos_tab) (void)hipFree(h->pos_tab);
     HIP_TRY(h, hipMalloc((void**)&h->pos_tab, (a + b + c + s) * sizeof(float)));
     h->chain_tab = h->pos_tab + a;
     h->t_tab = h->chain_tab + b;
@@ -710,14 +710,14 @@ int genie_profile_enable(genie_handle_t h, int enable) {
 
 int genie_profile_read(genie_handle_t h, const char** names, double* total_ms, int64_t* launches, int cap) {
     if (!h) return GENIE_E_ARG;
-    hipSetDevice(h->device);
+    (void)hipSetDevice(h->device);
     for (int i = 0; i < h->prof_n; ++i) {
         genie_ctx::ProfRec& r = h->prof_recs[i];
-        hipEventSynchronize(r.b);
+        (void)hipEventSynchronize(r.b);
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { h->prof_ms[r.cls] += ms; h->prof_cnt[r.cls] += 1; }
-        hipEventDestroy(r.a);
-        hipEventDestroy(r.b);
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
     }
     h->prof_n = 0;
     int n = 0;

@@ -1113,7 +1113,7 @@ bool launch_ipa_bias_hx(genie_ctx* h, hipStream_t st) {
     if (!w) return false;
     const int N = h->N, n_tiles = h->B * N * ((N + 31) / 32);
     const int grid = n_tiles / 4 < 2 * hx_num_cu() ? (n_tiles + 3) / 4 : 2 * hx_num_cu();      // 191 registers: two work-groups per CU
-    hipMemsetAsync(h->pmax, 0, sizeof(unsigned), st);
+    (void)hipMemsetAsync(h->pmax, 0, sizeof(unsigned), st);
     hipLaunchKernelGGL(k_ipa_bias_hx, dim3(grid), dim3(256), IB_UNITS * 2048 + 96 * 4, st, h->p, w->img, w->inv_s, h->ipa_bias_b, h->ipa_bias,
                        h->B, N, LH, n_tiles, (int)(h->hx_launches & 1), h->pmax);
     return true;

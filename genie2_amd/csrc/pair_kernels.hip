@@ -503,7 +503,7 @@ void launch_ipa_bias(genie_ctx* h, hipStream_t st) {
     const int N = h->N, ntile = (N + 127) / 128;
     const int LH = h->d.n_structure_layer * h->d.n_head_ipa;
     const size_t lds = 128 * LDZ * sizeof(float);
-    hipMemsetAsync(h->pmax, 0, sizeof(unsigned), st);
+    (void)hipMemsetAsync(h->pmax, 0, sizeof(unsigned), st);
     hipLaunchKernelGGL(k_ipa_bias, dim3(h->B * N * ntile), dim3(256), lds, st, h->p, h->ipa_bias_w, h->ipa_bias_b, h->ipa_bias,
                        h->B, N, LH, h->hx ? (int)(h->hx_launches & 1) : 0, h->pmax);
 }
@@ -514,8 +514,8 @@ void pair_hx_kernels_init();
 void pair_kernels_init() {
     pair_wl_kernels_init();
     pair_hx_kernels_init();
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_trimul_contract<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trimul_contract<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         2 * 2 * 128 * LDK * sizeof(float));
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_bias), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_bias), hipFuncAttributeMaxDynamicSharedMemorySize,
                         128 * LDZ * sizeof(float));
 }
