@@ -458,7 +458,7 @@ void launch_pair_transition_wl(genie_ctx* h, hipStream_t st, const PairLayerW& w
 void launch_trimul_hx(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgoing);
 void launch_trimul(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgoing) {
     if (h->hx) { launch_trimul_hx(h, st, w, outgoing); return; }
-    const int N = h->N, NP = h->NP, ntile = (N + 63) / 64;
+    const int NP = h->NP;
     {
         ProfScope ps(h, st, KC_TRIMUL_PROJ);
         launch_trimul_proj_wl(h, st, w, outgoing);
