@@ -453,6 +453,69 @@ def gen_train():
          unweighted_loss=unweighted_loss.detach(), weighted_loss=weighted_loss.detach(), grad_z_pred=z_pred.grad)
 
 
+def gen_train_grads(sd):
+    """Gradient of the training loss through the reference Denoiser (eval mode: the dropouts of structure_net.py:63-70 /
+    pair_transform_net.py are identities, so the result is a function of the inputs), for the backward kernels of the
+    training row to be checked against.  The quaternion signs of the reference's eigh are recorded and replayed."""
+    g = torch.Generator().manual_seed(99)
+    cfg = ref_config()
+    model = ref_denoiser(cfg, sd)
+    f = O.empty_features([16, 11], chains_per_sample=[[16], [5, 6]])
+    B, N = f['residue_mask'].shape
+    f['fixed_sequence_mask'][0, 2:6] = True
+    f['atom_positions'] = torch.randn(B, N, 3, generator=g) * 6 * f['residue_mask'].unsqueeze(-1)
+    T_ = cfg.diffusion['n_timestep']
+    betas = get_betas(T_, 'cosine')
+    ac = torch.cumprod(1. - betas, 0)
+    s = torch.tensor([700, 40])
+    z = torch.randn(B, N, 3, generator=g) * f['residue_mask'].unsqueeze(-1)
+    trans_s = torch.sqrt(ac)[s].view(-1, 1, 1) * f['atom_positions'] + torch.sqrt(1. - ac)[s].view(-1, 1, 1) * z
+    rots_s = compute_frenet_frames(trans_s, f['chain_index'], f['residue_mask'])
+    feats = O.prepare_features(f)
+    record = []
+    orig = ref_pfn.rot_to_quat
+
+    def rec_q(r):
+        q = orig(r)
+        record.append(q.detach())
+        return q
+
+    ref_pfn.rot_to_quat = rec_q
+    try:
+        out = model(T(rots_s, trans_s), s.int(), feats)
+    finally:
+        ref_pfn.rot_to_quat = orig
+    w = 2.0
+    rm, fs = f['residue_mask'], f['fixed_sequence_mask']
+    cm, im = rm * fs, rm * ~fs
+    cl = ref_mse(out['z'], z, cm, aggregate='sum')
+    il = ref_mse(out['z'], z, im, aggregate='sum')
+    loss = torch.mean((w * cl + il) / (w * torch.sum(cm, dim=-1) + torch.sum(im, dim=-1)))
+    loss.backward()
+    ref_grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    # the oracle restatement under autograd, same quaternion signs
+    codes = O.quat_sign_codes(record[0])
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    o = O.denoiser_forward(sdg, O.BASE_DIMS, rots_s, trans_s, s.int(), f, 'closed', codes)
+    lo = O.training_loss(o['z'], z, f, w)['weighted_loss']
+    lo.backward()
+    worst = 0.0
+    for k in ref_grads:
+        scale = max(float(ref_grads[k].abs().max()), 1e-6)
+        worst = max(worst, float((sdg[k].grad - ref_grads[k]).abs().max()) / scale)
+    print('  loss ref %.6f oracle %.6f; worst relative gradient difference %.2e over %d tensors' % (float(loss), float(lo), worst, len(ref_grads)))
+    assert abs(float(loss) - float(lo)) < 1e-5 and worst < 5e-3
+    keys = list(ref_grads.keys())
+    probe = {k: ref_grads[k].reshape(-1)[:8] for k in keys}
+    save('train_grads_n16_b2', atom_positions=f['atom_positions'], residue_mask=f['residue_mask'], chain_index=f['chain_index'],
+         residue_index=f['residue_index'], fixed_sequence_mask=f['fixed_sequence_mask'], num_residues=f['num_residues'],
+         lengths=np.array([16, 11]), chain_lengths=np.array([16, 0, 5, 6]), s=s, z=z, trans_s=trans_s, rots_s=rots_s,
+         quat_codes=codes, condition_loss_weight=np.float32(w), loss=loss.detach(), z_pred=out['z'].detach(),
+         keys=np.array(keys), grad_abs_max=np.array([float(ref_grads[k].abs().max()) for k in keys], dtype=np.float32),
+         grad_norm=np.array([float(ref_grads[k].norm()) for k in keys], dtype=np.float32),
+         grad_probe=np.stack([probe[k].numpy() if probe[k].numel() == 8 else np.pad(probe[k].numpy(), (0, 8 - probe[k].numel())) for k in keys]))
+
+
 def main():
     torch.manual_seed(0)
     print('weights (synthetic recipe, seed 0)')
@@ -472,7 +535,7 @@ def main():
         print('motif'); gen_motif(sd)
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'train':
-        print('train'); gen_train()
+        print('train'); gen_train(); gen_train_grads(sd)
         return
     print('schedule'); gen_schedule()
     print('encoding'); gen_encoding()
@@ -481,7 +544,7 @@ def main():
     gen_single_calls(sd)
     print('trajectory'); gen_trajectory(sd)
     print('motif'); gen_motif(sd)
-    print('train'); gen_train()
+    print('train'); gen_train(); gen_train_grads(sd)
 
 
 if __name__ == '__main__':

@@ -111,3 +111,27 @@ def test_training_step_ends_match_reference_golden():
     assert abs(float(lo['unweighted_loss'].detach()) - float(g['unweighted_loss'])) < 1e-7
     assert (lo['condition_losses'].detach() - t(g['condition_losses'])).abs().max() < 1e-5
     assert (zp.grad - t(g['grad_z_pred'])).abs().max() < 1e-8
+
+
+def test_training_gradients_match_reference_golden(base_weights):
+    """d weighted_loss / d parameter through the whole denoiser (eval mode): the oracle under torch autograd against the
+    gradients the reference Denoiser's own autograd produced (tests/golden/train_grads_n16_b2.npz, all 396 tensors:
+    largest magnitude, norm and the first 8 entries of each).  This is what the backward kernels of the training row
+    will be checked with."""
+    g = load_golden('train_grads_n16_b2')
+    f = _train_features(g)
+    sd = {k: v.clone().requires_grad_(True) for k, v in base_weights.items()}
+    o = O.denoiser_forward(sd, O.BASE_DIMS, t(g['rots_s']), t(g['trans_s']), t(g['s']).int(), f, 'closed', t(g['quat_codes']))
+    assert (o['z'].detach() - t(g['z_pred'])).abs().max() < 1e-4
+    lo = O.training_loss(o['z'], t(g['z']), f, float(g['condition_loss_weight']))['weighted_loss']
+    assert abs(float(lo.detach()) - float(g['loss'])) < 1e-5
+    lo.backward()
+    keys = [str(k) for k in g['keys']]
+    assert keys == list(sd.keys())
+    for i, k in enumerate(keys):
+        gr = sd[k].grad
+        scale = max(float(g['grad_abs_max'][i]), 1e-6)
+        assert abs(float(gr.abs().max()) - float(g['grad_abs_max'][i])) <= 5e-3 * scale, k
+        assert abs(float(gr.norm()) - float(g['grad_norm'][i])) <= 5e-3 * max(float(g['grad_norm'][i]), 1e-6), k
+        n = min(8, gr.numel())
+        assert (gr.reshape(-1)[:n] - t(g['grad_probe'][i][:n])).abs().max() <= 5e-3 * scale, k
