@@ -636,6 +636,14 @@ int genie_frenet(genie_handle_t h, genie_stream_t stream, const float* trans, fl
     return GENIE_OK;
 }
 
+int genie_adam_step(genie_stream_t stream, size_t n, float* p, const float* g, float* m, float* v, double lr, double beta1, double beta2,
+                    double eps, int step) {
+    if (!p || !g || !m || !v || step < 1) return GENIE_E_ARG;
+    if (n == 0) return GENIE_OK;
+    launch_adam((hipStream_t)stream, n, p, g, m, v, lr, beta1, beta2, eps, step);
+    return hipGetLastError() == hipSuccess ? GENIE_OK : GENIE_E_HIP;
+}
+
 int genie_q_sample(genie_handle_t h, genie_stream_t stream, const float* x0, const float* z, const float* c_x0, const float* c_z,
                    float* trans_out, float* rots_out) {
     if (!h || !h->have_feats) { if (h) SET_ERR(h, "genie_q_sample: no batch bound"); return h ? GENIE_E_STATE : GENIE_E_ARG; }

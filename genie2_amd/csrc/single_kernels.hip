@@ -1518,6 +1518,28 @@ __global__ void k_training_loss_mean(const float* __restrict__ stats, int B, flo
     }
 }
 
+// torch.optim.Adam's single-tensor update (ddpm.py:73-77), elementwise over a flat blob; bias corrections are computed on
+// the host in double as torch does
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, size_t n, float omb1, float b2, float omb2, float eps,
+                                              float step_size, float sqrt_bc2) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * omb1;                     // lerp_(grad, 1 - beta1), as torch writes exp_avg
+        const float vi = v[i] * b2 + omb2 * (gi * gi);                  // mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / sqrt_bc2 + eps;                 // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+        p[i] = p[i] - step_size * (mi / denom);                         // addcdiv_(exp_avg, denom, value=-step_size)
+    }
+}
+void launch_adam(hipStream_t st, size_t n, float* p, const float* g, float* m, float* v, double lr, double b1, double b2, double eps,
+                 int step) {
+    const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, p, g, m, v, n,
+                       (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps, (float)(lr / bc1), (float)sqrt(bc2));
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------

@@ -20,6 +20,17 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+def adam_step(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8):
+    """torch.optim.Adam's update (ddpm.py:73-77) in place on flat fp32 device tensors; `step` counts from 1."""
+    lib = capi.load_library()
+    for t in (p, g, m, v):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
+    rc = lib.genie_adam_step(C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream), p.numel(), _ptr(p), _ptr(g), _ptr(m), _ptr(v),
+                             float(lr), float(betas[0]), float(betas[1]), float(eps), int(step))
+    if rc != 0:
+        raise capi.GenieError('genie_adam_step failed (%d)' % rc)
+
+
 class GenieEngine:
     def __init__(self, dims, state_dict, device='cuda:0', n_pos=None, n_chain=None, math=None):
         self.lib = capi.load_library()

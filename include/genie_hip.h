@@ -187,6 +187,13 @@ int genie_q_sample(genie_handle_t h, genie_stream_t stream, const float* x0 /*[B
 int genie_training_loss(genie_handle_t h, genie_stream_t stream, const float* z_pred /*[B,N,3]*/, const float* z /*[B,N,3]*/,
                         float condition_loss_weight, float* losses_out, float* grad_out);
 
+/* One Adam update over a flat fp32 parameter blob (torch.optim.Adam as configured by ddpm.py:73-77: betas, eps,
+ * no weight decay, no amsgrad), all arrays on the device, `step` = 1 for the first update; the scalars are doubles because
+ * torch derives 1 - beta and the bias corrections in double before it rounds them:
+ *   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps). */
+int genie_adam_step(genie_stream_t stream, size_t n, float* p, const float* g, float* m, float* v, double lr, double beta1,
+                    double beta2, double eps, int step);
+
 /* ---- measurement ------------------------------------------------------- */
 
 /* Per-kernel-class HIP-event timing on the launch stream (bench.py roofline

@@ -402,3 +402,24 @@ def test_training_step_ends_match_reference_golden(base_engine):
     # no gradient requested: same losses
     out2 = base_engine.training_loss(t(g['z_pred']), t(g['z']), float(g['condition_loss_weight']), grad=False)
     assert float(out2['weighted_loss']) == float(out['weighted_loss']) and 'grad' not in out2
+
+
+def test_adam_step_matches_torch_adam():
+    """genie_adam_step against torch.optim.Adam with the reference's settings (ddpm.py:73-77: lr from the config,
+    default betas / eps, no weight decay), three consecutive updates of a flat blob."""
+    from genie2_amd.engine import adam_step
+    g0 = torch.Generator().manual_seed(3)
+    n = 100003
+    p_ref = torch.nn.Parameter(torch.randn(n, generator=g0))
+    opt = torch.optim.Adam([p_ref], lr=1e-4)
+    p = p_ref.detach().clone().cuda()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in (1, 2, 3):
+        grad = torch.randn(n, generator=g0) * (10.0 ** (step - 2))
+        p_ref.grad = grad.clone()
+        opt.step()
+        adam_step(p, grad.cuda(), m, v, 1e-4, step)
+        assert mdiff(p, p_ref.detach()) <= 2e-7, step
+    st = opt.state[p_ref]
+    assert mdiff(m, st['exp_avg']) <= 1e-6 * float(st['exp_avg'].abs().max())
+    assert mdiff(v, st['exp_avg_sq']) <= 1e-6 * float(st['exp_avg_sq'].abs().max())
