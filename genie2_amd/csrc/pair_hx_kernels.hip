@@ -986,7 +986,7 @@ static void trimul_slice(genie_ctx* h, HxSlice& v, const TriMulW& w, bool outgoi
     }
     {
         ProfScope ps(h, st, KC_TRIMUL_OUT, v.prof);
-        static const bool resident = getenv("GENIE_OUT_STREAMED") == nullptr;     // default: weights resident in LDS (0.233 vs 0.240 ms per launch)
+        const bool resident = getenv("GENIE_OUT_STREAMED") == nullptr;     // default: weights resident in LDS (0.233 vs 0.240 ms per launch)
         if (resident)
             hipLaunchKernelGGL(k_trimul_out_hx_r<8>, dim3(hx_grid((n_wt + 7) / 8, 8, v.cus)), dim3(512), 4 * HX_STAGE_BYTES, st, zs, xcm,
                                x.img_out, x.bgs, x.bzs, N, NP, n_wt, cm_bytes, z_bytes, x.sx, x.cgo, x.cz, (int)(v.launches++ & 1));

@@ -357,7 +357,8 @@ def test_sampler_api_end_to_end(tmp_path, base_weights):
 def test_fused_structure_tail_matches_separate_launches(base_engine, monkeypatch):
     """k_struct_rows_hx (split-K output projection summed on load, LayerNorm, transition, LayerNorm, BackboneUpdate in
     one launch) against the seven separate launches it replaces (GENIE_NO_STRUCT_FUSE): same arithmetic up to summation
-    order.  Ragged batch whose row count is not a multiple of the 32-row tile."""
+    order.  Ragged batch whose row count is not a multiple of the 32-row tile.  The other alternative forms the library keeps
+    behind switches are run on the same inputs."""
     f = O.empty_features([45, 23, 38])
     B, N = f['residue_mask'].shape
     g = torch.Generator().manual_seed(11)
@@ -374,12 +375,18 @@ def test_fused_structure_tail_matches_separate_launches(base_engine, monkeypatch
     monkeypatch.setenv('GENIE_IPA_Q8', '1')          # eight queries per 1024-thread attention work-group (opt-in form)
     z8 = base_engine.denoise(x, r, ts, None, taps=('s_final',))
     monkeypatch.delenv('GENIE_IPA_Q8', raising=False)
+    monkeypatch.setenv('GENIE_OUT_STREAMED', '1')    # TriMul output kernel with streamed weights, pair bias through the f32 kernel
+    monkeypatch.setenv('GENIE_IPA_BIAS_F32', '1')
+    zo = base_engine.denoise(x, r, ts, None, taps=('s_final',))
+    monkeypatch.delenv('GENIE_OUT_STREAMED', raising=False)
+    monkeypatch.delenv('GENIE_IPA_BIAS_F32', raising=False)
     m = f['residue_mask'].bool()           # padded rows attend through an all -1e5 bias: not comparable beyond summation order
     for k in ('z', 's_final'):
         a, b = zf[k].cpu()[m], zs[k].cpu()[m]
         assert torch.isfinite(a).all()
         assert mdiff(a, b) <= 4e-6 * max(1.0, float(b.abs().max())), k
         assert mdiff(z8[k].cpu()[m], a) <= 4e-6 * max(1.0, float(b.abs().max())), k
+        assert mdiff(zo[k].cpu()[m], a) <= 2e-5 * max(1.0, float(b.abs().max())), k
 
 
 def test_training_step_ends_match_reference_golden(base_engine):
