@@ -259,6 +259,7 @@ void launch_ipa_attn(genie_ctx* h, hipStream_t st, int layer, const float* head_
 void launch_q_sample(genie_ctx* h, hipStream_t st, const float* x0, const float* z, const float* c0, const float* c1, float* trans_out);
 void launch_training_loss(genie_ctx* h, hipStream_t st, const float* zp, const float* z, float w, float* losses, float* grad);
 void launch_adam(hipStream_t st, size_t n, float* p, const float* g, float* m, float* v, double lr, double b1, double b2, double eps, int step);
+void launch_any_nonzero(genie_ctx* h, hipStream_t st, const uint8_t* x, size_t n, unsigned* flag);
 bool launch_struct_tail(genie_ctx* h, hipStream_t st, const StructLayerW& S, const float* trans_in, float* z_out);
 void launch_bb_update(genie_ctx* h, hipStream_t st, const StructLayerW& w, const float* trans_in,
                       float* z_out);

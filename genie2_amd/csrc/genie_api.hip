@@ -536,7 +536,15 @@ int genie_prepare_features(genie_handle_t h, genie_stream_t stream, int B, int N
     HIP_TRY(h, hipMemsetAsync(h->acm, 0, (size_t)B * cp * NP * NP * 4, st));
     HIP_TRY(h, hipMemsetAsync(h->bcm, 0, (size_t)B * cp * NP * NP * 4, st));
     single_kernels_init(d, N);
-    h->has_motif = true;   // the motif term is evaluated unconditionally (once per batch; zero when no motif is set)
+    {   // does this batch condition on structure (any fixed_structure_mask entry set)?  If not, the motif term is identically
+        // zero and the step-invariant pair term is a table row per pair: k_pair_init looks it up instead of reading pstatic
+        unsigned any = 0;
+        HIP_TRY(h, hipMemsetAsync(h->pmax, 0, sizeof(unsigned), st));
+        launch_any_nonzero(h, st, h->f_fstm, P, h->pmax);
+        HIP_TRY(h, hipMemcpyAsync(&any, h->pmax, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipStreamSynchronize(st));
+        h->has_motif = any != 0;
+    }
     launch_pair_static(h, st);
     HIP_TRY(h, hipGetLastError());
     h->have_feats = true;

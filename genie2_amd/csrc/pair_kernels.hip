@@ -279,13 +279,21 @@ __device__ __forceinline__ void rot_to_quat_dev(const float* r, int code, float*
 // p = (p_i + p_j + static + W_t [bins | quat | fsm | fsm]) * mask
 // (pair_feature_net.py:117-160).  static = relpos + motif term (k_pair_static).
 #define LDF 52   // 48 features + 4 pad
+// TABLE: no motif / template terms in this batch -- the step-invariant part is then one of 2 k + 2 rows of the relative-position
+// table per pair (+ the same-chain row) and is looked up here instead of being read back from the 268-MB pstatic tensor
+// (the same expression as k_pair_static<false>, so the result is bit-identical).
+template <bool TABLE>
 __global__ __launch_bounds__(256) void k_pair_init(const float* __restrict__ trans, const float* __restrict__ rots,
                                                    const int8_t* __restrict__ codes, const float* __restrict__ rmask,
                                                    const uint8_t* __restrict__ fstm, const float* __restrict__ pij,
                                                    const float* __restrict__ pstatic, const float* __restrict__ wt,
-                                                   float* __restrict__ p, int N, float dmin, float dstep, int nbin) {
+                                                   float* __restrict__ p, int N, float dmin, float dstep, int nbin,
+                                                   const int32_t* __restrict__ ridx, const int32_t* __restrict__ cidx,
+                                                   const float* __restrict__ relpos_t, int relpos_k) {
     __shared__ __attribute__((aligned(16))) float ft[64 * LDF];
     __shared__ float pmk[64];
+    __shared__ int dsel[64];
+    __shared__ float same[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntile = (N + 63) >> 6;
     const int st = blockIdx.x % ntile;
@@ -321,6 +329,13 @@ __global__ __launch_bounds__(256) void k_pair_init(const float* __restrict__ tra
                 frow[nbin + 4] = f; frow[nbin + 5] = f;
                 for (int k = nbin + 6; k < 48; ++k) frow[k] = 0.f;
                 pmk[jl] = pm;
+                if (TABLE) {
+                    const bool sc = cidx[b * N + i] == cidx[b * N + j];
+                    int dd = ridx[b * N + i] - ridx[b * N + j] + relpos_k;
+                    dd = max(0, min(dd, 2 * relpos_k));
+                    dsel[jl] = sc ? dd : 2 * relpos_k + 1;
+                    same[jl] = sc ? 1.f : 0.f;
+                }
             }
         } else {
             for (int k = part; k < 48; k += 4) frow[k] = 0.f;
@@ -337,6 +352,7 @@ __global__ __launch_bounds__(256) void k_pair_init(const float* __restrict__ tra
     }
     const int ch = wave * 32 + (lane & 31);
     const float pi_c = pij[((size_t)b * N + i) * 256 + ch];
+    const float w_same = TABLE ? relpos_t[(2 * relpos_k + 2) * 128 + ch] : 0.f;
     const size_t prow0 = ((size_t)b * N + i) * N + t0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -347,7 +363,8 @@ __global__ __launch_bounds__(256) void k_pair_init(const float* __restrict__ tra
                 const float acc = hf ? a1[r] : a0[r];
                 const float pj_c = pij[((size_t)b * N + t0 + t) * 256 + 128 + ch];
                 const size_t o = (prow0 + t) * 128 + ch;
-                p[o] = (acc + pi_c + pj_c + pstatic[o]) * pmk[t];
+                const float stat = TABLE ? (relpos_t[dsel[t] * 128 + ch] + same[t] * w_same) + 0.f : pstatic[o];
+                p[o] = (acc + pi_c + pj_c + stat) * pmk[t];
             }
         }
     }
@@ -429,6 +446,16 @@ __global__ __launch_bounds__(256) void k_pair_static(const float* __restrict__ p
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
+__global__ void k_any_nonzero(const uint8_t* __restrict__ x, size_t n, unsigned* __restrict__ flag) {
+    unsigned any = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) any |= x[i];
+    if (any) atomicOr(flag, 1u);
+}
+void launch_any_nonzero(genie_ctx* h, hipStream_t st, const uint8_t* x, size_t n, unsigned* flag) {
+    ProfScope ps(h, st, KC_MISC);
+    hipLaunchKernelGGL(k_any_nonzero, dim3(256), dim3(256), 0, st, x, n, flag);
+}
+
 void launch_pair_static(genie_ctx* h, hipStream_t st) {
     ProfScope ps(h, st, KC_PAIR_STATIC);
     const int N = h->N, ntile = (N + 63) / 64;
@@ -446,9 +473,14 @@ void launch_pair_static(genie_ctx* h, hipStream_t st) {
 void launch_pair_init(genie_ctx* h, hipStream_t st, const float* trans, const float* rots, const int8_t* codes) {
     ProfScope ps(h, st, KC_PAIR_INIT);
     const int N = h->N, ntile = (N + 63) / 64;
-    hipLaunchKernelGGL(k_pair_init, dim3(h->B * N * ntile), dim3(256), 0, st, trans, rots, codes, h->rmaskf, h->f_fstm,
-                       h->pij, h->pstatic, h->templ_w, h->p, N, h->d.template_dist_min, h->d.template_dist_step,
-                       h->d.template_dist_n_bin);
+    if (!h->has_motif && !getenv("GENIE_PAIR_STATIC_READ"))
+        hipLaunchKernelGGL(k_pair_init<true>, dim3(h->B * N * ntile), dim3(256), 0, st, trans, rots, codes, h->rmaskf, h->f_fstm,
+                           h->pij, h->pstatic, h->templ_w, h->p, N, h->d.template_dist_min, h->d.template_dist_step,
+                           h->d.template_dist_n_bin, h->f_ridx, h->f_cidx, h->relpos_t, h->d.relpos_k);
+    else
+        hipLaunchKernelGGL(k_pair_init<false>, dim3(h->B * N * ntile), dim3(256), 0, st, trans, rots, codes, h->rmaskf, h->f_fstm,
+                           h->pij, h->pstatic, h->templ_w, h->p, N, h->d.template_dist_min, h->d.template_dist_step,
+                           h->d.template_dist_n_bin, h->f_ridx, h->f_cidx, h->relpos_t, h->d.relpos_k);
 }
 
 void launch_trimul_proj_wl(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgoing);
