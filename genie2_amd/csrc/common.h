@@ -226,7 +226,7 @@ struct genie_ctx {
     // workspace (one allocation, carved)
     void* ws; size_t ws_bytes;
     float *p, *acm, *bcm, *xcm, *pstatic, *ipa_bias;
-    float *spart;                 // [3][B N][c_s] split-K slices of the IPA output projection
+    float *spart;                 // [3][B N][c_s] split-K slices of the IPA output projection (SR_KSPLIT)
     unsigned *pmax;               // bits of max |p| over the pair tensor the IPA layers read (k_ipa_bias -> k_ipa_attn_q)
     float *xsingle, *s0, *s, *s1, *s2, *h1, *h2, *pij, *proj, *cat;
     float *kT, *v, *qp, *kpT, *vp;

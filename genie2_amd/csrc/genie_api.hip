@@ -508,7 +508,7 @@ int genie_prepare_features(genie_handle_t h, genie_stream_t stream, int B, int N
     want(&h->kT, M * H * C * 4); want(&h->v, M * H * C * 4); want(&h->qp, M * H * Pq * 3 * 4);
     want(&h->kpT, M * H * Pq * 3 * 4); want(&h->vp, M * H * Pv * 3 * 4);
     want(&h->rots_w, M * 9 * 4); want(&h->trans_w, M * 3 * 4); want(&h->loop_z, M * 3 * 4);
-    want(&h->tsteps, (size_t)B * 4); want(&h->rmaskf, M * 4); want(&h->pmax, 4); want(&h->spart, 3 * M * cs * 4);
+    want(&h->tsteps, (size_t)B * 4); want(&h->rmaskf, M * 4); want(&h->pmax, 4); want(&h->spart, 3 * M * cs * 4);      // SR_KSPLIT slices
     want(&h->f_aatype, M * 20 * 4); want(&h->f_rmask, M * 4); want(&h->f_ridx, M * 4); want(&h->f_cidx, M * 4);
     want(&h->f_pos, M * 3 * 4); want(&h->f_fsm, M); want(&h->f_fstm, P); want(&h->f_ifm, M);
     size_t total = 0;

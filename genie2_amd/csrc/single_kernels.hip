@@ -740,7 +740,8 @@ __global__ __launch_bounds__(256) void k_bb_update(const float* __restrict__ s, 
 // out of the LDS tile instead of HBM, and writes its result tile in place once the last chunk has been split.
 // ---------------------------------------------------------------------------
 #define SR_PD 4
-#define SR_KSPLIT 3          // split-K slices of the IPA output projection summed by the loader
+#define SR_KSPLIT 3          // split-K slices of the IPA output projection summed by the loader (nsplit is 0 or this;
+                             // 6 slices: output projection + tail 0.120 -> 0.126 ms per layer, the loader's extra reads cost more)
 #define SR_LD 388            // floats per row of an activation tile (384 + 4: the two half-waves of a D store hit disjoint banks)
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_struct_rows_hx(
@@ -804,29 +805,36 @@ __global__ __launch_bounds__(NW * 64) void k_struct_rows_hx(
     // of a thread's four float4 is issued before the first is used
     {
         constexpr int NI = 32 * (C / 4) / NT;
-        static_assert(32 * (C / 4) % NT == 0 && SR_KSPLIT == 3, "loader shape");
-        float4 v[NI], w1[NI], w2[NI], rq[NI], bq[NI];
+        static_assert(32 * (C / 4) % NT == 0, "loader shape");
+        constexpr int NB = SR_KSPLIT <= 3 ? NI : 2;   // float4 per thread and batch: (SR_KSPLIT + 2) NB loads in flight
+        static_assert(NI % NB == 0, "loader batches");
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int u = tid + i * NT, r = u / (C / 4), q = u - r * (C / 4);
-            const size_t o = (size_t)min(r0 + r, M - 1) * C + q * 4;
-            v[i] = *reinterpret_cast<const float4*>(x + o);
-            if (nsplit) {
-                w1[i] = *reinterpret_cast<const float4*>(x + zstride + o);
-                w2[i] = *reinterpret_cast<const float4*>(x + 2 * zstride + o);
-                rq[i] = *reinterpret_cast<const float4*>(xres + o);
-                bq[i] = *reinterpret_cast<const float4*>(xbias + q * 4);
-            }
-        }
+        for (int i0 = 0; i0 < NI; i0 += NB) {
+            float4 v[NB], w[SR_KSPLIT - 1][NB], rq[NB], bq[NB];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int u = tid + i * NT, r = u / (C / 4), q = u - r * (C / 4);
-            float4 t = v[i];
-            if (nsplit) {
-                t.x = (((t.x + w1[i].x) + w2[i].x) + bq[i].x) + rq[i].x; t.y = (((t.y + w1[i].y) + w2[i].y) + bq[i].y) + rq[i].y;
-                t.z = (((t.z + w1[i].z) + w2[i].z) + bq[i].z) + rq[i].z; t.w = (((t.w + w1[i].w) + w2[i].w) + bq[i].w) + rq[i].w;
+            for (int i = 0; i < NB; ++i) {
+                const int u = tid + (i0 + i) * NT, r = u / (C / 4), q = u - r * (C / 4);
+                const size_t o = (size_t)min(r0 + r, M - 1) * C + q * 4;
+                v[i] = *reinterpret_cast<const float4*>(x + o);
+                if (nsplit) {
+#pragma unroll
+                    for (int zz = 1; zz < SR_KSPLIT; ++zz) w[zz - 1][i] = *reinterpret_cast<const float4*>(x + zz * zstride + o);
+                    rq[i] = *reinterpret_cast<const float4*>(xres + o);
+                    bq[i] = *reinterpret_cast<const float4*>(xbias + q * 4);
+                }
             }
-            *reinterpret_cast<float4*>(T0 + r * SR_LD + q * 4) = t;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int u = tid + (i0 + i) * NT, r = u / (C / 4), q = u - r * (C / 4);
+                float4 t = v[i];
+                if (nsplit) {
+#pragma unroll
+                    for (int zz = 1; zz < SR_KSPLIT; ++zz) { t.x += w[zz - 1][i].x; t.y += w[zz - 1][i].y; t.z += w[zz - 1][i].z; t.w += w[zz - 1][i].w; }
+                    t.x = (t.x + bq[i].x) + rq[i].x; t.y = (t.y + bq[i].y) + rq[i].y;
+                    t.z = (t.z + bq[i].z) + rq[i].z; t.w = (t.w + bq[i].w) + rq[i].w;
+                }
+                *reinterpret_cast<float4*>(T0 + r * SR_LD + q * 4) = t;
+            }
         }
     }
     // frames of the tile's rows (R 9 floats, t 3) for the composition at the end: fetched now, used 40 us later
