@@ -33,7 +33,7 @@ __device__ __forceinline__ float hx_load(rsrc_t r, int voff, int soff) {
 #ifndef HX_ABL
 #define HX_ABL 0          // developer builds (tools/abl_build.sh): 128 = in-kernel timestamps; 0 in the product
 #endif
-#if HX_ABL & 128          // in-kernel timestamps of every wave of work-group 0 (tools/ts_read.py)
+#if HX_ABL & 128          // in-kernel timestamps of every wave of work-group 0 (tests/devtools/ts_read.py)
 __device__ unsigned long long g_hx_ts[24][4096];   // [variant * 8 + wave]
 #define HX_TS_DECL(variant) const bool ts_on = blockIdx.x == 0; \
                    unsigned long long* ts_p = g_hx_ts[(variant) * 8 + (threadIdx.x >> 6)]; int ts_n = 0
@@ -41,7 +41,7 @@ __device__ unsigned long long g_hx_ts[24][4096];   // [variant * 8 + wave]
 extern "C" int genie_hx_debug_read(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hx_ts), sizeof(unsigned long long) * 24 * 4096);
 }
-#if HX_ABL & 256          // finer stamps: per k-chunk in the projection (tools/ts_kc.py), inside the transition's first GEMM (tools/ts_tr.py)
+#if HX_ABL & 256          // finer stamps: per k-chunk in the projection (tests/devtools/ts_kc.py), inside the transition's first GEMM (tests/devtools/ts_tr.py)
 #define HX_TS2() HX_TS()
 #else
 #define HX_TS2() do { } while (0)

@@ -2,7 +2,7 @@
 import os
 import sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import genie_oracle as O          # noqa: E402
 from genie2_amd.engine import GenieEngine     # noqa: E402
 

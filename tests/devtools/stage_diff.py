@@ -1,6 +1,6 @@
 """Developer aid (GPU box): print per-stage max differences HIP vs oracle.
 
-    python tools/stage_diff.py [--base] [--n 40]
+    python tests/devtools/stage_diff.py [--base] [--n 40]
 """
 import argparse
 import os
@@ -9,7 +9,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import genie_oracle as O  # noqa: E402
 from genie2_amd.engine import GenieEngine  # noqa: E402
 

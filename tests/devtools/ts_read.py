@@ -1,7 +1,7 @@
 """Developer aid (GPU box): read the in-kernel timestamps of an HX_ABL=128 build after one denoiser call and
 print the mean duration of each phase of k_trimul_proj_hx (the last launch overwrites earlier ones).
 
-    GENIE_MATH=hx GENIE_HIP_LIB=genie2_amd/lib/abl/libgenie_abl128.so python tools/ts_read.py
+    GENIE_MATH=hx GENIE_HIP_LIB=genie2_amd/lib/abl/libgenie_abl128.so python tests/devtools/ts_read.py
 """
 import ctypes as C
 import os
@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import genie_oracle as O  # noqa: E402
 from genie2_amd import capi  # noqa: E402
 from genie2_amd.engine import GenieEngine  # noqa: E402

@@ -2,7 +2,7 @@
 after k-chunk 0, after k-chunk 3, after GEMM1, after split+GEMM2, after barrier."""
 import ctypes as C, os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import genie_oracle as O
 from genie2_amd import capi
 from genie2_amd.engine import GenieEngine
