@@ -19,7 +19,10 @@ MFMAs per f32 product at 2.5 PFLOP/s; --math f32: v_mfma_f32 at 157.3 TFLOP/s).
 `traffic` = HBM bytes per launch from the committed rocprofv3 FETCH_SIZE /
 WRITE_SIZE passes (profiles/), null if that kernel was not profiled.
 `cpu_baseline` times the oracle (the CPU restatement of the reference) on this
-host for one step of the same workload.
+host: 1 warm-up + 3 timed consecutive steps of the same workload, median.
+At N=1 the same line also carries `value_f32` (the same K steps in the exact-f32
+MFMA kernels), `hx_vs_f32` (distance of the two trajectories after those steps)
+and `full_loop` (all T=1000 reverse steps of one batch, timed end to end).
 """
 import argparse
 import json
@@ -39,7 +42,7 @@ from genie2_amd import features as F  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0     # same table, "Peak BF16/FP16 MFMA", dense
 PEAK_HBM_GBS = 8000.0
-PMC_TRAFFIC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
+PMC_TRAFFIC = [os.path.join(ROOT, 'profiles', n) for n in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json')]   # newest first
 KERNEL_OF_CLASS = {'trimul_proj': 'k_trimul_proj', 'trimul_contract': 'k_trimul_contract', 'trimul_out': 'k_trimul_out',
                    'pair_transition': 'k_pair_transition'}
 
@@ -52,13 +55,28 @@ def algorithmic_bytes(dims, B, N):
 
 
 def measured_traffic(cls, math):
-    """HBM bytes per launch from the committed PMC passes (None when this kernel was not profiled)."""
-    try:
-        d = json.load(open(PMC_TRAFFIC))[math]
-    except (OSError, KeyError, ValueError):
-        return None
-    v = [k for name, k in d.items() if name.startswith(KERNEL_OF_CLASS[cls])]
-    return sum(x['hbm_read_bytes'] + x['hbm_write_bytes'] for x in v) / len(v) if v else None
+    """(HBM bytes per launch, source file) from the newest committed PMC passes that profiled this kernel (`kernels_sha` in the
+    file names the csrc/ state it was taken on; a mismatch with the running library is reported as stale)."""
+    for path in PMC_TRAFFIC:
+        try:
+            blob = json.load(open(path))
+            d = blob[math]
+        except (OSError, KeyError, ValueError):
+            continue
+        v = [k for name, k in d.items() if name.startswith(KERNEL_OF_CLASS[cls])]
+        if v:
+            return sum(x['hbm_read_bytes'] + x['hbm_write_bytes'] for x in v) / len(v), os.path.basename(path), blob.get('kernels_sha')
+    return None, None, None
+
+
+def kernels_sha():
+    """sha256 over the kernel sources the library is built from (profiles/ files carry it so stale traffic numbers are visible)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'genie2_amd', 'csrc')
+    for n in sorted(os.listdir(d)):
+        h.update(open(os.path.join(d, n), 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def algorithmic_flops(dims, B, N):
@@ -81,35 +99,51 @@ def step_flops(dims, B, N):
 
 
 def host_cores():
-    """CPU cores this process may actually use: affinity, capped by the cgroup
-    quota (a GPU box exposes every core of the host but grants a share)."""
+    """(cores, how) this process may actually use: scheduler affinity, capped by the cgroup CPU quota (a GPU box exposes every
+    core of the host but grants a share).  GENIE_BENCH_CPU_THREADS overrides."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    how = 'sched_getaffinity'
     for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
         try:
             txt = open(path).read().split()
             if path.endswith('cpu.max'):
                 if txt[0] != 'max':
-                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+                    q = max(1, int(int(txt[0]) / int(txt[1]) + 0.5))
+                    if q < n:
+                        n, how = q, 'cgroup cpu.max quota'
             else:
                 q = int(txt[0])
                 per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
-                if q > 0:
-                    n = min(n, max(1, int(q / per + 0.5)))
+                if q > 0 and max(1, int(q / per + 0.5)) < n:
+                    n, how = max(1, int(q / per + 0.5)), 'cgroup cfs quota'
             break
         except (OSError, ValueError, IndexError):
             continue
     env = os.environ.get('GENIE_BENCH_CPU_THREADS')
     if env:
-        n = int(env)
+        n, how = int(env), 'GENIE_BENCH_CPU_THREADS'
     elif n > 64:
-        n = 16      # no quota visible on a many-core host: use the documented 1-GPU CPU share
-    return n
+        # no quota visible on a many-core host: the pool documents 16 cores per GPU, so that is what the baseline gets
+        n, how = 16, 'assumed: the documented 16-core share of a 1-GPU box (affinity shows %d, no cgroup quota)' % n
+    return n, how
 
 
-def cpu_baseline(dims, B, N, seed):
-    """One step of the same workload through the oracle on the host cores."""
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(dims, B, N, seed, n_timed=3):
+    """The same workload through the oracle (CPU restatement of the reference) on the host cores: consecutive reverse-loop
+    steps T, T-1, ... of one batch, 1 untimed warm-up step then `n_timed` timed ones; value = 1 / median step time."""
     from oracle import genie_oracle as O
-    torch.set_num_threads(host_cores())
+    cores, how = host_cores()
+    torch.set_num_threads(cores)
     sd = pack.random_state_dict(dims, seed=0)
     f = O.empty_features([N] * B)
     g = torch.Generator().manual_seed(seed)
@@ -117,16 +151,22 @@ def cpu_baseline(dims, B, N, seed):
     fr = O.prepare_features(f)
     rots = O.compute_frenet_frames(trans, fr['chain_index'], fr['residue_mask'])
     sched = O.setup_schedule(dims['n_timestep'])
-    step = dims['n_timestep']
-    ts = torch.full((B,), step, dtype=torch.int32)
-    t0 = time.time()
+    times = []
     with torch.no_grad():
-        z = O.denoiser_forward(sd, dims, rots, trans, ts, f, 'eigh')['z']
-        O.p_sample_step(sched, step, 0.6, trans, z, torch.randn(B, N, 3, generator=g), fr)
-    dt = time.time() - t0
-    return {'value': 1.0 / dt, 'unit': 'batch-steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'1 reverse-loop step (denoiser + posterior + Frenet) at N={N}, batch={B}, fp32, '
-                      f'oracle/genie_oracle.py with torch.linalg.eigh quaternions, {dt:.1f} s wall'}
+        for i in range(1 + n_timed):
+            step = dims['n_timestep'] - i
+            ts = torch.full((B,), step, dtype=torch.int32)
+            t0 = time.perf_counter()
+            z = O.denoiser_forward(sd, dims, rots, trans, ts, f, 'eigh')['z']
+            trans, rots = O.p_sample_step(sched, step, 0.6, trans, z, torch.randn(B, N, 3, generator=g), fr)
+            times.append(time.perf_counter() - t0)
+    timed = sorted(times[1:])
+    med = timed[len(timed) // 2]
+    return {'value': 1.0 / med, 'unit': 'batch-steps/s', 'cores': torch.get_num_threads(), 'cores_source': how,
+            'cpu_model': cpu_model(), 'kind': 'port',
+            'step_seconds': {'warmup': round(times[0], 2), 'timed': [round(x, 2) for x in times[1:]], 'median': round(med, 2)},
+            'sample': f'{n_timed} consecutive reverse-loop steps (denoiser + posterior + Frenet) after 1 warm-up step at N={N}, '
+                      f'batch={B}, fp32, oracle/genie_oracle.py with torch.linalg.eigh quaternions; median {med:.1f} s per step'}
 
 
 def main():
@@ -137,6 +177,7 @@ def main():
     ap.add_argument('--length', type=int, default=256)
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra-legs', action='store_true', help='skip the other-arithmetic and full T=1000 legs (N=1 only)')
     ap.add_argument('--profile-steps', type=int, default=3)
     ap.add_argument('--math', choices=['hx', 'f32'], default=None, help='pair-stack arithmetic (default: library default, hx)')
     args = ap.parse_args()
@@ -167,25 +208,28 @@ def main():
     eng.bind_features(feats)
     g = torch.Generator().manual_seed(42 + rank)
     P = max(1, args.profile_steps)
-    noise = torch.randn(K + W + 1 + P, B, N, 3, generator=g).to(dev)   # draws of iterations 0..K+W(+P) (base.py:227,269)
+    noise = torch.randn(T, B, N, 3, generator=g).to(dev)   # draws of the whole loop: 1 initial + one per step but the last (base.py:227,269)
 
     def barrier():
         if dist:
             td.barrier()
         torch.cuda.synchronize(dev)
 
-    state = None
-    if W > 0:
-        tr, ro, _ = eng.sample_loop(noise, 0.6, first_step=T, last_step=T - W + 1)
-        state = (tr, ro)
-    else:
-        tr = noise[0].clone()
-        state = (tr, eng.frenet(tr))
-    barrier()
-    t0 = time.perf_counter()
-    tr, ro, _ = eng.sample_loop(noise, 0.6, first_step=T - W, last_step=T - W - K + 1, state=state)
-    barrier()
-    dt = time.perf_counter() - t0
+    def timed_leg():
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides"""
+        if W > 0:
+            tr, ro, _ = eng.sample_loop(noise, 0.6, first_step=T, last_step=T - W + 1)
+            state = (tr, ro)
+        else:
+            tr = noise[0].clone()
+            state = (tr, eng.frenet(tr))
+        barrier()
+        t0 = time.perf_counter()
+        tr, ro, _ = eng.sample_loop(noise, 0.6, first_step=T - W, last_step=T - W - K + 1, state=state)
+        barrier()
+        return time.perf_counter() - t0, tr, ro
+
+    dt, tr, ro = timed_leg()
     if dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
@@ -224,7 +268,9 @@ def main():
             else:
                 ach = mfma_flop / launch_s / 1e12
                 r = {'bound': 'mfma', 'kernel': cls, 'achieved': ach, 'peak': mfma_peak, 'unit': 'TFLOP/s', 'frac': ach / mfma_peak}
-            r.update({'traffic': measured_traffic(cls, math), 'avg_launch_ms': kern[cls]['ms_per_launch'],
+            traffic, tsrc, tsha = measured_traffic(cls, math)
+            r.update({'traffic': traffic, 'traffic_source': tsrc, 'traffic_stale': (tsha != kernels_sha()) if traffic else None,
+                      'avg_launch_ms': kern[cls]['ms_per_launch'],
                       'algorithmic_bytes_per_launch': nbytes, 'algorithmic_flop_per_launch': flops[cls],
                       'matrix_flop_per_launch': mfma_flop, 'floor_ms': {'hbm': t_hbm * 1e3, 'mfma': t_mfma * 1e3}})
             return r
@@ -248,6 +294,26 @@ def main():
             'finite': finite, 'roofline': roof, 'other_pair_kernel_rooflines': other_roofs,
             'kernels': {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in kern.items()},
         }
+        if world == 1 and not args.no_extra_legs:
+            # (1) the same K steps in the exact-f32 MFMA kernels, from the same noise: rate, and how far the two arithmetics are apart
+            other = 'f32' if math == 'hx' else 'hx'
+            eng.set_math(other)
+            dt2, tr2, _ = timed_leg()
+            eng.set_math(math)
+            rms = float(tr.pow(2).mean().sqrt())
+            dx = float((tr - tr2).abs().max())
+            out['value_' + other] = K / dt2
+            out['ms_per_step_' + other] = dt2 / K * 1e3
+            out['hx_vs_f32'] = {'max_abs_dx_after_steps': dx, 'steps': K + W, 'coordinate_rms': rms, 'ratio': dx / rms,
+                                'tolerance_ratio': 1e-4}
+            # (2) the metric's whole job once: all T reverse steps of one batch, timed end to end (frames, draws and loop included)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            trf, _, _ = eng.sample_loop(noise, 0.6)
+            torch.cuda.synchronize(dev)
+            dtf = time.perf_counter() - t0
+            out['full_loop'] = {'steps': T, 'seconds': dtf, 'batch_steps_per_s': T / dtf, 'structure_steps_per_s': T * B / dtf,
+                                'finite': bool(torch.isfinite(trf).all().item()), 'math': math}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(dims, B, N, 42)
             out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']

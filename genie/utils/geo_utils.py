@@ -1,1 +1,1 @@
-from genie2_amd.geometry import compute_frenet_frames  # noqa: F401
+from genie2_amd.engine import compute_frenet_frames  # noqa: F401

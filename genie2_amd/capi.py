@@ -39,7 +39,8 @@ class GenieFeatures(C.Structure):
 
 
 class GenieTaps(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ('s', 'p', 's_final', 'rots_out', 'trans_out', 'p_init', 'p_layer0', 'states')]
+    _fields_ = [(k, C.c_void_p) for k in ('s', 'p', 's_final', 'rots_out', 'trans_out', 'p_init', 'p_layer0', 'states', 'p_trimul_out0',
+                                              'ipa_cat0')]
 
 
 # name -> (restype, argtypes); every symbol include/genie_hip.h declares
@@ -52,6 +53,7 @@ SYMBOLS = {
     'genie_set_tables': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'genie_prepare_features': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(GenieFeatures)]),
     'genie_frenet': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'genie_frenet_frames': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'genie_denoise': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.POINTER(GenieTaps)]),
     'genie_q_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

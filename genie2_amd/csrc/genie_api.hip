@@ -478,6 +478,7 @@ int genie_prepare_features(genie_handle_t h, genie_stream_t stream, int B, int N
     if (!h->have_weights) { SET_ERR(h, "genie_prepare_features: weights not loaded"); return GENIE_E_STATE; }
     const genie_dims_t& d = h->d;
     if (ipa_attn_lds(d, N) > 160 * 1024) { SET_ERR(h, "N = %d exceeds the attention kernel's LDS budget", N); return GENIE_E_ARG; }
+    if ((size_t)24 * N * sizeof(float) > 160 * 1024) { SET_ERR(h, "N = %d exceeds the Frenet kernel's LDS budget (96 B per residue)", N); return GENIE_E_ARG; }
     {   // the pair kernels address [B,N,N,128] f32 tensors with 32-bit buffer offsets (SGPR soffset + VGPR voffset)
         const size_t np = (size_t)((N + 31) / 32 * 32);
         const size_t pair_bytes = (size_t)B * np * np * d.c_p * sizeof(float);
@@ -578,6 +579,7 @@ static int denoise_internal(genie_ctx* h, hipStream_t st, const float* trans, co
     // pair transform net
     for (int l = 0; l < d.n_pair_transform_layer; ++l) {
         launch_trimul(h, st, h->pair[l].out, true);
+        if (l == 0 && taps && taps->p_trimul_out0) HIP_TRY(h, d2d(taps->p_trimul_out0, h->p, P * cp * 4));
         launch_trimul(h, st, h->pair[l].in, false);
         launch_pair_transition(h, st, h->pair[l]);
         if (l == 0 && taps && taps->p_layer0) HIP_TRY(h, d2d(taps->p_layer0, h->p, P * cp * 4));
@@ -597,6 +599,7 @@ static int denoise_internal(genie_ctx* h, hipStream_t st, const float* trans, co
             launch_gemm_rows(h, st, h->s, cs, M, cs, S.proj_w, nproj, S.proj_b, nullptr, 0, nullptr, 0, h->proj, nproj);
             launch_ipa_prep(h, st);
             launch_ipa_attn(h, st, l, S.head_w);
+            if (blk == 0 && l == 0 && taps && taps->ipa_cat0) HIP_TRY(h, d2d(taps->ipa_cat0, h->cat, (size_t)M * ncat * 4));
             auto state_tap = [&]() -> hipError_t {
                 return (taps && taps->states) ? d2d(taps->states + (size_t)(n_state++) * M * cs, h->s, (size_t)M * cs * 4) : hipSuccess;
             };

@@ -1,5 +1,6 @@
 // Single-track kernels: single feature net, row GEMMs, LayerNorm, invariant
 // point attention, backbone update.  Reference lines are cited per kernel.
+#include <algorithm>
 #include <type_traits>
 #include "hx.h"
 
@@ -1727,6 +1728,19 @@ void launch_frenet(genie_ctx* h, hipStream_t st, int mode, int step, float scale
                        al, sa, so, sb, scale);
 }
 
+// handle-free form: compute_frenet_frames(coords, chains, mask) of genie/utils/geo_utils.py:21-85 as the reference calls it
+int genie_frenet_frames(genie_stream_t stream, int B, int N, const float* coords, const int32_t* chains, const int32_t* mask,
+                        float* rots_out) {
+    if (!coords || !chains || !mask || !rots_out || B < 1 || N < 2) return GENIE_E_ARG;
+    const size_t lds = (size_t)24 * N * sizeof(float);
+    if (lds > 160 * 1024) return GENIE_E_ARG;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_p_sample_frenet), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_p_sample_frenet, dim3(B), dim3(256), lds, (hipStream_t)stream, 0, const_cast<float*>(coords), rots_out,
+                       (const float*)nullptr, (const float*)nullptr, mask, chains, N, 1.f, 1.f, 1.f, 0.f, 0.f);
+    return hipGetLastError() == hipSuccess ? GENIE_OK : GENIE_E_HIP;
+}
+
 void launch_fill_i32(genie_ctx* h, hipStream_t st, int32_t* p, int n, int v) {
     ProfScope ps(h, st, KC_MISC);
     hipLaunchKernelGGL(k_fill_i32, dim3((n + 255) / 256), dim3(256), 0, st, p, n, v);
@@ -1738,6 +1752,9 @@ void launch_scale_copy(genie_ctx* h, hipStream_t st, const float* in, float* out
 }
 
 void single_kernels_init(const genie_dims_t& d, int n_max) {
+    // compute_frenet_frames keeps one structure in LDS (24 floats per residue): past 64 KiB the launch needs the attribute
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_p_sample_frenet), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)std::min<size_t>((size_t)24 * n_max * sizeof(float), 160 * 1024));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_struct_rows_hx<12>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)struct_rows_lds());
     if (ipa_is_base(d)) {

@@ -46,12 +46,12 @@ def load_pretrained_model(rootdir, name, epoch):
     basedir = os.path.join(rootdir, name)
     if not os.path.exists(basedir):
         print('Base directory not found at ' + basedir)
-        raise SystemExit(0)
+        raise SystemExit(1)          # the reference exits with 0 here (model_io.py:150-152); a missing model is a failure
     config = Config(os.path.join(basedir, 'configuration'))
     ckpt = os.path.join(basedir, 'checkpoints', 'epoch.{}.ckpt'.format(epoch))
     if not os.path.exists(ckpt):
         print('Missing checkpoint file: ' + ckpt)
-        raise SystemExit(0)
+        raise SystemExit(1)
     return Genie.load_from_checkpoint(ckpt, config)
 
 

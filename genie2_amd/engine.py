@@ -31,6 +31,23 @@ def adam_step(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8):
         raise capi.GenieError('genie_adam_step failed (%d)' % rc)
 
 
+def compute_frenet_frames(coords, chains, mask):
+    """genie/utils/geo_utils.py:21-85 with the reference's own signature: coords [B,N,3] on a GPU, chains / mask [B,N]."""
+    if not coords.is_cuda:
+        raise capi.GenieError('compute_frenet_frames runs on the GPU (libgenie_hip); there is no CPU path')
+    lib = capi.load_library()
+    x = coords.to(torch.float32).contiguous()
+    ch = chains.to(device=x.device, dtype=torch.int32).contiguous()
+    mk = mask.to(device=x.device, dtype=torch.int32).contiguous()
+    B, N = x.shape[:2]
+    rots = torch.empty(B, N, 3, 3, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.genie_frenet_frames(C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream), B, N, _ptr(x), _ptr(ch), _ptr(mk), _ptr(rots))
+    if rc != 0:
+        raise capi.GenieError('genie_frenet_frames failed (%d)' % rc)
+    return rots
+
+
 class GenieEngine:
     def __init__(self, dims, state_dict, device='cuda:0', n_pos=None, n_chain=None, math=None):
         self.lib = capi.load_library()
@@ -140,7 +157,8 @@ class GenieEngine:
         z = torch.empty(B, N, 3, device=self.device)
         shapes = {'s': (B, N, self.dims['c_s']), 'p': (B, N, N, self.dims['c_p']), 's_final': (B, N, self.dims['c_s']),
                   'rots_out': (B, N, 3, 3), 'trans_out': (B, N, 3), 'p_init': (B, N, N, self.dims['c_p']),
-                  'p_layer0': (B, N, N, self.dims['c_p']),
+                  'p_layer0': (B, N, N, self.dims['c_p']), 'p_trimul_out0': (B, N, N, self.dims['c_p']),
+                  'ipa_cat0': (B, N, self.dims['n_head_ipa'] * (self.dims['c_hidden_ipa'] + 4 * self.dims['n_v_point'] + self.dims['c_p'])),
                   'states': (1 + self.dims['n_structure_block'] * self.dims['n_structure_layer'], B, N, self.dims['c_s'])}
         out = {k: torch.empty(shapes[k], device=self.device) for k in taps}
         ct = capi.GenieTaps(**{k: v.data_ptr() for k, v in out.items()})

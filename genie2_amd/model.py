@@ -75,16 +75,21 @@ class Denoiser(nn.Module):
             self._engine = GenieEngine(self.dims, {k: v for k, v in self.state_dict().items()}, dev)
         return self._engine
 
+    _BIND_KEYS = ('residue_mask', 'residue_index', 'chain_index', 'aatype', 'atom_positions',
+                  'fixed_sequence_mask', 'fixed_structure_mask', 'interface_mask')
+
     def bind(self, features):
         """Bind a batch of features (done implicitly by forward; the step-invariant
-        pair terms are recomputed only when the feature tensors change)."""
+        pair terms are recomputed only when the feature tensors change).  "Unchanged" means
+        the very same tensor objects at the same in-place version: the bound tensors are
+        kept alive here, so an address can not be recycled by a different batch."""
         eng = self.engine()
-        sig = tuple((k, features[k].data_ptr(), tuple(features[k].shape), features[k]._version)
-                    for k in ('residue_mask', 'residue_index', 'chain_index', 'aatype', 'atom_positions',
-                              'fixed_sequence_mask', 'fixed_structure_mask', 'interface_mask'))
-        if sig != self._bound:
+        cur = [features[k] for k in self._BIND_KEYS]
+        same = (self._bound is not None and len(self._bound) == len(cur)
+                and all(t is b and t._version == v for t, (b, v) in zip(cur, self._bound)))
+        if not same:
             eng.bind_features(features)
-            self._bound = sig
+            self._bound = [(t, t._version) for t in cur]
         return eng
 
     def forward(self, ts, timesteps, features, outputs=('z',), quat_codes=None):

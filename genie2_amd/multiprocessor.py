@@ -43,3 +43,8 @@ class MultiProcessor(ABC):
             p.start()
         for p in procs:
             p.join()
+        # unlike the reference (multiprocessor.py:97-100, exit codes dropped) a dead worker is an error here: there is no CPU
+        # fallback behind the HIP path, so a partial outdir must not look like success
+        failed = [(i, p.exitcode) for i, p in enumerate(procs) if p.exitcode != 0]
+        if failed:
+            raise RuntimeError('worker(s) failed: ' + ', '.join('cuda:%d exit code %s' % f for f in failed))

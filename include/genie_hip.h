@@ -81,6 +81,8 @@ typedef struct {
     float* p_init;     /* [B,N,N,c_p]    pair feature net output (test tap)    */
     float* p_layer0;   /* [B,N,N,c_p]    after pair transform layer 0 (tap)    */
     float* states;     /* [1+blocks*layers,B,N,c_s] 'states' (structure_net.py:236-243) */
+    float* p_trimul_out0; /* [B,N,N,c_p] p after layer 0's outgoing triangle multiplication (pair_transform_net.py:109-110; tap) */
+    float* ipa_cat0;   /* [B,N,H*(c_hidden+4*Pv+c_p)] input of layer 0's IPA linear_out (invariant_point_attention.py:251-258; tap) */
 } genie_taps_t;
 
 /* ---- lifetime ---------------------------------------------------------- */
@@ -124,6 +126,11 @@ int genie_prepare_features(genie_handle_t h, genie_stream_t stream, int B, int N
 /* compute_frenet_frames (genie/utils/geo_utils.py:21-85) for the bound batch. */
 int genie_frenet(genie_handle_t h, genie_stream_t stream, const float* trans /*[B,N,3]*/,
                  float* rots_out /*[B,N,3,3]*/);
+
+/* The same without a handle, as the reference's callers use it: compute_frenet_frames(coords, chains, mask)
+ * (genie/utils/geo_utils.py:21; callers sampler/base.py:228,282, diffusion/genie.py:86).  chains / mask: int32 [B,N]. */
+int genie_frenet_frames(genie_stream_t stream, int B, int N, const float* coords /*[B,N,3]*/, const int32_t* chains,
+                        const int32_t* mask, float* rots_out /*[B,N,3,3]*/);
 
 /* Denoiser.forward (genie/model/model.py:125-192): z_out[B,N,3].
  * timesteps: device int32 [B].  quat_codes: optional device int8 [B,N,N]

@@ -49,5 +49,6 @@ def base_engine(base_weights):
     from oracle import genie_oracle as O
     from genie2_amd.engine import GenieEngine
     eng = GenieEngine(dict(O.BASE_DIMS), base_weights, 'cuda:0')
+    eng._test_weights = base_weights
     yield eng
     eng.close()

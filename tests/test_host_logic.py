@@ -261,3 +261,37 @@ def test_asm_register_rings_are_not_touched_by_the_compiler(tmp_path):
     assert chk.returncode == 0 and ' 0 violations' in chk.stdout, chk.stdout[-2000:]
     n_loads = int(chk.stdout.split(':')[-1].split('asm loads')[0])
     assert n_loads >= 40          # both kernels' rings were actually found
+
+
+def test_multiprocessor_spawn_path_and_exit_codes(tmp_path):
+    """MultiProcessor.run with num_devices=2 (genie/utils/multiprocessor.py:73-100): one spawned child per device, contiguous
+    bins of ceil(n/2) tasks, every task executed exactly once; a dying worker makes run() raise (the reference drops exit codes)."""
+    import json
+    from _mp_stub import StubRunner
+    params = dict(min_length=50, max_length=130, length_step=16, outdir=str(tmp_path))
+    StubRunner().run(params, 2, sequential_order=True)
+    got = {n: json.load(open(tmp_path / n)) for n in sorted(os.listdir(tmp_path))}
+    assert sorted(got) == ['cuda_0.json', 'cuda_1.json']
+    assert [t['length'] for t in got['cuda_0.json']['tasks']] == [130, 114, 98]
+    assert [t['length'] for t in got['cuda_1.json']['tasks']] == [82, 66, 50]
+    assert got['cuda_0.json']['pid'] != got['cuda_1.json']['pid'] != os.getpid()
+    # shuffled order (the default): same multiset of tasks
+    for n in got:
+        os.unlink(tmp_path / n)
+    StubRunner().run(params, 2)
+    lens = sorted(t['length'] for n in os.listdir(tmp_path) for t in json.load(open(tmp_path / n))['tasks'])
+    assert lens == [50, 66, 82, 98, 114, 130]
+    with pytest.raises(RuntimeError, match='cuda:1 exit code 3'):
+        StubRunner().run(dict(params, fail_on='cuda:1'), 2)
+
+
+def test_missing_checkpoint_exits_non_zero(tmp_path):
+    from genie2_amd.diffusion import load_pretrained_model
+    with pytest.raises(SystemExit) as e:
+        load_pretrained_model(str(tmp_path), 'nope', 1)
+    assert e.value.code == 1
+    (tmp_path / 'm').mkdir()
+    (tmp_path / 'm' / 'configuration').write_text('name m\n')
+    with pytest.raises(SystemExit) as e:
+        load_pretrained_model(str(tmp_path), 'm', 1)
+    assert e.value.code == 1
