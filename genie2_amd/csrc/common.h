@@ -151,7 +151,7 @@ __device__ __forceinline__ void ln_rows_128(float* tile, int ld, const float* __
 enum KernelClass {
     KC_SINGLE_INPUT = 0, KC_GEMM_ROWS, KC_LAYERNORM, KC_PAIR_STATIC, KC_PAIR_INIT,
     KC_TRIMUL_PROJ, KC_TRIMUL_CONTRACT, KC_TRIMUL_OUT, KC_PAIR_TRANSITION,
-    KC_IPA_BIAS, KC_IPA_PREP, KC_IPA_ATTN, KC_BB_UPDATE, KC_STRUCT_ROWS, KC_P_SAMPLE, KC_MISC, KC_COUNT
+    KC_IPA_BIAS, KC_IPA_PREP, KC_IPA_ATTN, KC_BB_UPDATE, KC_STRUCT_ROWS, KC_P_SAMPLE, KC_MISC, KC_PAIR_FUSED_A, KC_PAIR_FUSED_B, KC_COUNT
 };
 
 // "hx" images (hx.h): weights split in f16 halves, in stage order, + the scales that go with them
@@ -162,6 +162,8 @@ struct HxTriW {
     float *bias_proj, *bgs, *bzs;              // scaled biases (initial accumulators)
     float sx, cpa, cpb, cg, cx, cgo, cz;       // operand scale / epilogue rescales
 };
+// weight stream of one fused row-local chain (pair_fused_kernels.hip): stages O (4) | T (n_hb) | P (8), chained k order
+struct HxFusedW { const unsigned char* img; };
 struct TriMulW {
     float *proj_w;            // packed [512][128]: a_p | b_p | a_g | b_g
     float *proj_b;            // [512] same order
@@ -174,6 +176,7 @@ struct PairLayerW {
     TriMulW out, in;
     float *pt_ln_g, *pt_ln_b, *pt_w1, *pt_b1, *pt_w2, *pt_b2;   // w1 packed [512][128], w2 packed [128][512]
     HxTransW hx_pt;
+    HxFusedW fa, fb;          // chain A: out-output -> in-projections;  chain B: in-output -> transition -> next block's out-projections
 };
 struct StructLayerW {
     float *proj_w, *proj_b;       // packed [1152][384]: q | kv | q_pts | kv_pts
@@ -253,6 +256,7 @@ void launch_pair_init(genie_ctx* h, hipStream_t st, const float* trans, const fl
                       const int8_t* codes);
 void launch_trimul(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgoing);
 void launch_pair_transition(genie_ctx* h, hipStream_t st, const PairLayerW& w);
+bool launch_pair_stack_fused(genie_ctx* h, hipStream_t st, float* tap_trimul_out0, float* tap_layer0);   // false: not applicable, use the launches above
 void launch_ipa_bias(genie_ctx* h, hipStream_t st);
 void launch_ipa_prep(genie_ctx* h, hipStream_t st);
 void launch_ipa_attn(genie_ctx* h, hipStream_t st, int layer, const float* head_w);

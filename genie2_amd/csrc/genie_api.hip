@@ -13,6 +13,7 @@
 #include "common.h"
 
 void pair_kernels_init();
+void pair_fused_kernels_init();
 void single_kernels_init(const genie_dims_t& d, int n_max);
 void launch_scale_copy(genie_ctx* h, hipStream_t st, const float* in, float* out, int n, float s);
 size_t ipa_attn_lds(const genie_dims_t& d, int N);
@@ -25,7 +26,8 @@ static char g_create_err[512] = "";
 
 static const char* kKernelNames[KC_COUNT] = {
     "single_input", "gemm_rows", "layernorm_rows", "pair_static", "pair_init", "trimul_proj", "trimul_contract",
-    "trimul_out", "pair_transition", "ipa_bias", "ipa_prep", "ipa_attn", "bb_update", "struct_rows", "p_sample_frenet", "misc"};
+    "trimul_out", "pair_transition", "ipa_bias", "ipa_prep", "ipa_attn", "bb_update", "struct_rows", "p_sample_frenet", "misc",
+    "pair_fused_a", "pair_fused_b"};
 
 // ------------------------------------------------------------------ profiling
 void prof_begin(genie_ctx* h, hipStream_t st, int cls) {
@@ -99,6 +101,7 @@ int genie_create(const genie_dims_t* dims, int device, genie_handle_t* out) {
     h->pair = new PairLayerW[dims->n_pair_transform_layer > 0 ? dims->n_pair_transform_layer : 1]();
     h->st = new StructLayerW[dims->n_structure_layer]();
     pair_kernels_init();
+    pair_fused_kernels_init();
     {   // GENIE_MATH=f32: exact-f32 MFMA kernels; default: split-f16 ("hx", same accuracy class, see hx.h)
         const char* m = getenv("GENIE_MATH");
         h->hx = !(m && !strcmp(m, "f32"));
@@ -291,6 +294,10 @@ int genie_load_weights(genie_handle_t h, const float* blob, size_t n_floats) {
         slot(&h->templ_w, img.pack(t.data(), (int)cp, 48));
         slot(&h->motif_w, img.pack(m.data(), (int)cp, 40));
     }
+    struct TmSave { std::vector<float> w, gw, zw; float sp, sg, sgo, szo; };
+    struct PtSave { std::vector<float> w1v, w2; float s1, s2; };
+    std::vector<TmSave> tm_save(2 * (size_t)d.n_pair_transform_layer);
+    std::vector<PtSave> pt_save(d.n_pair_transform_layer);
     for (int l = 0; l < d.n_pair_transform_layer; ++l) {
         PairLayerW& L = h->pair[l];
         for (int dir = 0; dir < 2; ++dir) {
@@ -350,6 +357,7 @@ int genie_load_weights(genie_handle_t h, const float* blob, size_t n_floats) {
                 for (size_t r = 0; r < cp; ++r) { bgs[r] = gb[r] * HX_SX * sgo; bzs[r] = zb[r] * HX_SX * szo; }
                 slot(&X.bias_proj, img.raw(bp.data(), bp.size()));
                 slot(&X.bgs, img.raw(bgs.data(), cp)); slot(&X.bzs, img.raw(bzs.data(), cp));
+                tm_save[2 * l + dir] = TmSave{w, gw, zw, sp, sg, sgo, szo};
             }
             // the affine now lives in the weights: kernels that still take gamma / beta get (1, 0)
             slot(&T.ln_in_g, ones_off); slot(&T.ln_in_b, zeros_off);
@@ -382,8 +390,50 @@ int genie_load_weights(genie_handle_t h, const float* blob, size_t n_floats) {
             for (size_t r = 0; r < nh; ++r) b1s[r] = b1v[r] * HX_SX * s1;
             for (size_t r = 0; r < cp; ++r) b2s[r] = b2[r] * sh * s2;
             slot(&X.b1s, img.raw(b1s.data(), nh)); slot(&X.b2s, img.raw(b2s.data(), cp));
+            pt_save[l] = PtSave{w1v, std::vector<float>(w2, w2 + cp * nh), s1, s2};
         }
         slot(&L.pt_w2, img.pack(w2, (int)cp, (int)nh)); slot(&L.pt_b2, img.raw(b2, cp));
+    }
+    {   // fused row-local chains (pair_fused_kernels.hip): the same scaled weights, every unit in the chained k order
+        //   k = 16 kc + (e & 3) + 8 (e >> 2) + 4 hh   (the order in which a result tile's registers are the next B operand)
+        auto ck = [](int kc, int hh, int e) { return 16 * kc + (e & 3) + 8 * (e >> 2) + 4 * hh; };
+        auto emit_O = [&](const TmSave& t) {          // stages W_z{0,1}, W_z{2,3}, W_g{0,1}, W_g{2,3}; unit = 8 (block within the stage) + k-chunk
+            for (int which = 0; which < 2; ++which)
+                for (int st = 0; st < 2; ++st)
+                    for (int obl = 0; obl < 2; ++obl)
+                        for (int kc = 0; kc < 8; ++kc) {
+                            const std::vector<float>& m = which == 0 ? t.zw : t.gw;
+                            const float sc = which == 0 ? t.szo : t.sgo;
+                            const size_t ob = 2 * st + obl;
+                            hx.unit([&](int i, int hh, int e) { return m[(32 * ob + i) * cp + ck(kc, hh, e)] * sc; });
+                        }
+        };
+        auto emit_T = [&](const PtSave& t) {          // per hidden block: 8 units of W1 (k-chunks), 8 of W2 (chunk c, output block ob) at 8 + 4c + ob
+            const size_t nh = (size_t)d.pair_transition_n * cp;
+            for (size_t hb = 0; hb < nh / 32; ++hb) {
+                for (int kc = 0; kc < 8; ++kc)
+                    hx.unit([&](int i, int hh, int e) { return t.w1v[(32 * hb + i) * cp + ck(kc, hh, e)] * t.s1; });
+                for (int cc = 0; cc < 2; ++cc)
+                    for (int ob = 0; ob < 4; ++ob)
+                        hx.unit([&](int j, int hh, int e) { return t.w2[(size_t)(32 * ob + j) * nh + 32 * hb + ck(cc, hh, e)] * t.s2; });
+            }
+        };
+        auto emit_P = [&](const TmSave& t) {          // 8 passes: unit 2kc = the pass's projection rows, 2kc + 1 = its gate rows
+            for (size_t pass = 0; pass < 8; ++pass)
+                for (int kc = 0; kc < 8; ++kc) {
+                    hx.unit([&](int i, int hh, int e) { return t.w[(32 * pass + i) * cp + ck(kc, hh, e)] * t.sp; });
+                    hx.unit([&](int i, int hh, int e) { return t.w[(2 * ch + 32 * pass + i) * cp + ck(kc, hh, e)] * t.sg; });
+                }
+        };
+        for (int l = 0; l < d.n_pair_transform_layer; ++l) {
+            hxfix.push_back({&h->pair[l].fa.img, hx.begin()});
+            emit_O(tm_save[2 * l]); emit_P(tm_save[2 * l + 1]);
+            h->pair[l].fb.img = nullptr;
+            if (l + 1 < d.n_pair_transform_layer) {
+                hxfix.push_back({&h->pair[l].fb.img, hx.begin()});
+                emit_O(tm_save[2 * l + 1]); emit_T(pt_save[l]); emit_P(tm_save[2 * l + 2]);
+            }
+        }
     }
     const size_t H = d.n_head_ipa, C = d.c_hidden_ipa, Pq = d.n_qk_point, Pv = d.n_v_point;
     const size_t ncat = ipa_cat_n(d);
@@ -577,7 +627,8 @@ static int denoise_internal(genie_ctx* h, hipStream_t st, const float* trans, co
     if (taps && taps->p_init) HIP_TRY(h, d2d(taps->p_init, h->p, P * cp * 4));
 
     // pair transform net
-    for (int l = 0; l < d.n_pair_transform_layer; ++l) {
+    const bool fused = launch_pair_stack_fused(h, st, taps ? taps->p_trimul_out0 : nullptr, taps ? taps->p_layer0 : nullptr);
+    for (int l = 0; l < (fused ? 0 : d.n_pair_transform_layer); ++l) {
         launch_trimul(h, st, h->pair[l].out, true);
         if (l == 0 && taps && taps->p_trimul_out0) HIP_TRY(h, d2d(taps->p_trimul_out0, h->p, P * cp * 4));
         launch_trimul(h, st, h->pair[l].in, false);

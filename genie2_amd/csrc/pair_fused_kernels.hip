@@ -1,0 +1,477 @@
+// Row-local chains of the pair transform net fused into ONE persistent kernel per chain (hx arithmetic, hx.h):
+//
+//   chain A (inside a block):   TriMul-outgoing output  ->  TriMul-incoming projections
+//   chain B (across blocks):    TriMul-incoming output  ->  PairTransition + end-of-block mask  ->  next block's
+//                               TriMul-outgoing projections
+//   (pair_transform_net.py:109-119, modules/triangular_multiplicative_update.py:99-108, modules/pair_transition.py:48-56)
+//
+// Both chains act on one pair row at a time, so a wave keeps its 32-pair tile in registers from the x / z loads to the
+// stores: z is read once and written once per chain, the transition's input never exists in HBM, and the matrix-bound
+// transition runs inside the same kernel as the memory-bound output / projection phases.
+//
+// Orientation: lane = pair in EVERY phase.  Activations are always the B operand of v_mfma_f32_32x32x16_f16 and weights the
+// A operand (rows = output features), so every result tile is D[feature][pair]: lane (p, h) holds, for its pair p, features
+// (r & 3) + 8 (r >> 2) + 4 h of each 32-block.  Registers 8c' .. 8c' + 7 of such a tile are exactly the B fragment of k-chunk
+// 2 ob + c' in the "chained" k order  k = 16 c + (e & 3) + 8 (e >> 2) + 4 h  (hx.h), so a result feeds the next GEMM with no
+// data movement; the host packs every weight of these kernels with that k permutation, and x / z are loaded straight into it.
+// LayerNorm is an in-lane reduction plus one exchange with lane ^ 32.
+//
+// Tile = 32 pairs along the contiguous index of the channel-major images: ROW tiles (b, i, j0..j0+31) for chain B, COLUMN tiles
+// (b, i0..i0+31, j) for chain A (whose TriMul-outgoing contraction is launched with a and b swapped, so that it leaves x^T and
+// every x / a / b access of both chains is a 128-B run).  z rows are moved through a per-wave LDS staging area in whole
+// 256-B pieces in both directions (hx_zt_dma on the way in, fz_store_half on the way out).
+//
+// Stage stream per tile (32-KiB LDS-DMA stages, double buffered, one barrier each, 48 MFMAs per wave and stage):
+//   O: W_z{0,1}  W_z{2,3}  W_g{0,1}  W_g{2,3}   |   T: n_hb hidden blocks (W1 block + W2 block)   |   P: 8 projection passes
+#include "hx_pair.h"
+
+#define FZ_SB_BZ 0
+#define FZ_SB_BG 128
+#define FZ_SB_B1 256
+#define FZ_SB_B2 768
+#define FZ_SB_BP 896
+#define FZ_SB_FLOATS 1408
+#define FZ_LDS_BYTES (2 * HX_STAGE_BYTES + 6144 + 8 * HX_ZT_BYTES)
+#define FZ_OOR 0x7FFFFFF0
+#ifndef FZ_SAFE
+#define FZ_SAFE 0
+#endif
+#define FZ_FULL_WAIT(bit) do { if (FZ_SAFE & (bit)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); else asm volatile("" ::: "memory"); } while (0)
+
+struct FusedArgs {
+    float* z; const float* xcm; const float* rmask; const unsigned char* wimg;
+    const float *bzs, *bgs, *b1s, *b2s, *bproj;
+    unsigned *acm, *bcm;
+    int N, NP, n_wtiles, n_hb;
+    unsigned cm_bytes, z_bytes;
+    float sx, cgo, cz, c1, c2, inv_c2, cpa, cpb, cg;
+    int rev;
+};
+
+// granules (16 B = 4 channels) g and g + 2 of this lane's row: the chained-k slots e = 0..3 / 4..7 of k-chunk 4 half + q
+__device__ __forceinline__ void fz_zt_read(float4 (&raw)[16], const unsigned char* zt, int pl, int h, int half) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int g = 4 * q + h;
+        raw[2 * (4 * half + q)] = *reinterpret_cast<const float4*>(zt + pl * 256 + ((g ^ (pl & 15)) << 4));
+        raw[2 * (4 * half + q) + 1] = *reinterpret_cast<const float4*>(zt + pl * 256 + (((g + 2) ^ (pl & 15)) << 4));
+    }
+}
+
+// One channel half (64 channels = accumulators 2 hf, 2 hf + 1) of a result tile -> the wave's staging area in row order ->
+// global memory in whole 256-B pieces (the inverse of hx_zt_dma / fz_zt_read; rows >= nvalid are dropped).
+__device__ __forceinline__ void fz_store_half(rsrc_t rz, unsigned char* zt, const f32x16& v0, const f32x16& v1, int lane, int soff,
+                                              int row_stride, int nvalid, int hf) {
+    const int pl = lane & 31, h = lane >> 5;
+    FZ_FULL_WAIT(1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x16& v = (q < 2) ? v0 : v1;
+        const int r0 = 8 * (q & 1);
+        const int g = 4 * q + h;
+        *reinterpret_cast<float4*>(zt + pl * 256 + ((g ^ (pl & 15)) << 4)) = make_float4(v[r0], v[r0 + 1], v[r0 + 2], v[r0 + 3]);
+        *reinterpret_cast<float4*>(zt + pl * 256 + (((g + 2) ^ (pl & 15)) << 4)) = make_float4(v[r0 + 4], v[r0 + 5], v[r0 + 6], v[r0 + 7]);
+    }
+    hx_lds_done();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = 4 * j + (lane >> 4);
+        u32x4 d = *reinterpret_cast<const u32x4*>(zt + j * 1024 + lane * 16);
+        const int g = (lane & 15) ^ (r & 15);
+        const int voff = r < nvalid ? r * row_stride + (g << 4) : FZ_OOR;
+        __builtin_amdgcn_raw_buffer_store_b128(d, rz, voff, soff + hf * 256, 0);
+        // A store of more than 64 bits reads its data registers for a few cycles after it issues; a VALU write of them in the very
+        // next instruction corrupts the stored value (observed on gfx950: hipcc re-used dword 0 of `d` as an address temporary right
+        // behind the store and put no wait state between -- some tiles came out with rows of the next piece).  The empty-bodied asm
+        // keeps `d` allocated until two wait states behind the store.
+        asm volatile("s_nop 1" : "+v"(d) : : "memory");
+    }
+    FZ_FULL_WAIT(2);
+}
+
+// LayerNorm statistics of a result tile (this lane's 64 channels + its partner's): mean and sx / sqrt(var + eps)
+__device__ __forceinline__ void fz_stats(const f32x16 (&v)[4], float sx, float& mean, float& sc) {
+    float s = 0.f;
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += v[ob][r];
+    s += __shfl_xor(s, 32);
+    mean = s * (1.0f / 128.0f);
+    float ss = 0.f;
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float d = v[ob][r] - mean; ss += d * d; }
+    ss += __shfl_xor(ss, 32);
+    sc = sx / sqrtf(ss * (1.0f / 128.0f) + GENIE_LN_EPS);
+}
+__device__ __forceinline__ void fz_split_tile(h8 (&zh)[8], h8 (&zl)[8], const f32x16 (&v)[4], float mean, float sc) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = v[c >> 1][8 * (c & 1) + e] - mean;
+        hx_split8(x, sc, zh[c], zl[c]);
+    }
+}
+
+template <bool COL, bool HAS_T>
+__global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
+    float* sb = reinterpret_cast<float*>(smb + 2 * HX_STAGE_BYTES);
+    const int lane = threadIdx.x & 63, wave = UNI(threadIdx.x >> 6);
+    const int h = lane >> 5, pl = lane & 31;
+    const int N = A.N, NP = A.NP, n_wtiles = A.n_wtiles;
+    const int ntile = (N + 31) >> 5;
+    const int n_tiles = (n_wtiles + 7) / 8;
+    const int rev = A.rev;
+    const int n_hb = HAS_T ? A.n_hb : 0;
+    const int PBASE = 4 + n_hb;                              // first projection stage of the image
+    const rsrc_t rw = hx_rsrc(A.wimg, (unsigned)((PBASE + 8) * HX_STAGE_BYTES));
+    const rsrc_t rx = hx_rsrc(A.xcm, A.cm_bytes), rz = hx_rsrc(A.z, A.z_bytes);
+    const rsrc_t ra = hx_rsrc(A.acm, A.cm_bytes), rb = hx_rsrc(A.bcm, A.cm_bytes);
+    const int lane16 = lane * 16;
+    const int sstride = NP * NP * 4;                         // bytes per channel of a channel-major image
+    const int zstride = COL ? N * 512 : 512;                 // bytes between consecutive pairs of a tile
+    auto issue = [&](int s, int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = 4 * wave + q;
+            hx_dma(rw, smb + buf * HX_STAGE_BYTES + p * 1024, lane16, s * HX_STAGE_BYTES + p * 1024);
+        }
+    };
+    unsigned char* zt = smb + 2 * HX_STAGE_BYTES + 6144 + wave * HX_ZT_BYTES;
+    // wave-tile 8 tile + wave (clamped): z byte offset of its first row, valid rows, channel-major element offset of (channel 0, pair 0)
+    auto tile_geom = [&](int tile, int& zsoff, int& nv, int& cmoff) {
+        const int wt = min(HX_PHYS(tile) * 8 + wave, n_wtiles - 1);
+        const int st = wt % ntile, line = (wt / ntile) % N, b = wt / (ntile * N);
+        nv = min(32, N - st * 32);
+        zsoff = COL ? ((b * N + st * 32) * N + line) * 512 : ((b * N + line) * N + st * 32) * 512;
+        cmoff = ((b * 128 * NP + line) * NP + st * 32) * 4;
+    };
+    // L2 touch of the next tile's inputs, one dword per 128-B line: part 0 = its 128 x lines (one per channel), part 1 = the 128
+    // lines of its 32 z rows.  Two wave instructions each, nothing kept; issued in the last two projection passes.
+    auto fz_touch_next = [&](int next_tile, int part) {
+        int zs, nv, cm;
+        tile_geom(next_tile, zs, nv, cm);
+        float t0, t1;
+        if (part == 0) {
+            t0 = hx_load(rx, lane * sstride, cm);
+            t1 = hx_load(rx, (64 + lane) * sstride, cm);
+        } else {
+            const int r0 = min(lane >> 2, nv - 1), r1 = min(16 + (lane >> 2), nv - 1);
+            t0 = hx_load(rz, r0 * zstride + (lane & 3) * 128, zs);
+            t1 = hx_load(rz, r1 * zstride + (lane & 3) * 128, zs);
+        }
+        asm volatile("" :: "v"(t0), "v"(t1));
+    };
+    const int vx = (4 * h * NP * NP + pl) * 4;              // x_cm voffset: channel block of this half-wave, pair pl
+    // x of chunk c: raw[2c] = channels 16c + 4h + {0..3}, raw[2c+1] = 16c + 8 + 4h + {0..3}
+#define FZ_XLOAD(c, xoff) do {                                                                                              \
+        raw[2 * (c)].x = hx_load(rx, vx, (xoff) + (16 * (c) + 0) * sstride); raw[2 * (c)].y = hx_load(rx, vx, (xoff) + (16 * (c) + 1) * sstride); \
+        raw[2 * (c)].z = hx_load(rx, vx, (xoff) + (16 * (c) + 2) * sstride); raw[2 * (c)].w = hx_load(rx, vx, (xoff) + (16 * (c) + 3) * sstride); \
+        raw[2 * (c) + 1].x = hx_load(rx, vx, (xoff) + (16 * (c) + 8) * sstride); raw[2 * (c) + 1].y = hx_load(rx, vx, (xoff) + (16 * (c) + 9) * sstride); \
+        raw[2 * (c) + 1].z = hx_load(rx, vx, (xoff) + (16 * (c) + 10) * sstride); raw[2 * (c) + 1].w = hx_load(rx, vx, (xoff) + (16 * (c) + 11) * sstride); \
+    } while (0)
+
+    int tile = blockIdx.x;
+    issue(0, 0);
+    for (int u = threadIdx.x; u < FZ_SB_FLOATS; u += 512) {
+        float v = 0.f;
+        if (u < FZ_SB_BG) v = A.bzs[u];
+        else if (u < FZ_SB_B1) v = A.bgs[u - FZ_SB_BG];
+        else if (u < FZ_SB_B2) { if (HAS_T && u - FZ_SB_B1 < n_hb * 32) v = A.b1s[u - FZ_SB_B1]; }
+        else if (u < FZ_SB_BP) { if (HAS_T) v = A.b2s[u - FZ_SB_B2]; }
+        else v = A.bproj[u - FZ_SB_BP];
+        sb[u] = v;
+    }
+    hx_stage_landed();
+    __syncthreads();
+
+#pragma unroll 1
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int wt_raw = HX_PHYS(tile) * 8 + wave;
+        const bool act = wt_raw < n_wtiles;
+        const int wt = act ? wt_raw : n_wtiles - 1;          // idle waves shadow the last tile (stores dropped)
+        const int st = wt % ntile, line = (wt / ntile) % N, b = wt / (ntile * N);
+        const int t0i = st * 32;
+        const int nvalid = act ? min(32, N - t0i) : 0;
+        int zsoff, znv, cmoff;
+        tile_geom(tile, zsoff, znv, cmoff);
+        // hipcc hoists loop-invariant LDS loads (the accumulators' initial biases: ~60 values) out of the tile loop and then spills
+        // them; an offset it can not see through keeps them where they are used
+        int bo = 0;
+        asm volatile("" : "+v"(bo));
+        const float* sbt = sb + bo;
+        int lane_t = lane;                                    // likewise for the ~40 swizzled staging addresses derived from the lane id
+        asm volatile("" : "+v"(lane_t));
+        const int pl_t = lane_t & 31, h_t = lane_t >> 5;
+        // the tile's inputs: x straight into (chained-order) registers, z rows through the staging area.  Nothing of a tile is held
+        // across the previous tile's phases (registers: every phase runs at ~190-230 live values per lane); what hides the HBM
+        // latency here is the L2 touch the previous tile's projection phase made for exactly these lines (fz_touch_next).
+        float4 raw[16];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) FZ_XLOAD(c, cmoff);
+        hx_zt_dma(rz, zt, lane_t, zsoff, zstride, znv, 0);
+        const float msk = (pl < nvalid) ? A.rmask[b * N + line] * A.rmask[b * N + t0i + pl] : 0.f;
+        const bool more = tile + (int)gridDim.x < n_tiles;
+        hx_vm_done();
+        f32x16 v[4];                                          // the tile's running value: update -> z' -> (z'' accumulators) -> z''
+
+        // ------------------------------------------------------------------ O: z' = z + (W_z LN(x) + b_z) sigmoid(W_g LN(z) + b_g)
+        {
+            h8 xh[8], xl[8];
+            hx_norm_split(xh, xl, raw, A.sx);                 // (raw = x; dead from here on)
+            PIPE_FENCE();
+            float4 rawz[16];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {            // stages 0, 1: update accumulators of channel blocks 2 half, 2 half + 1
+                issue(half + 1, half ^ 1);
+                const unsigned char* stage = smb + half * HX_STAGE_BYTES;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    v[2 * half][r] = sbt[FZ_SB_BZ + (2 * half) * 32 + acc_row(r, lane)];
+                    v[2 * half + 1][r] = sbt[FZ_SB_BZ + (2 * half + 1) * 32 + acc_row(r, lane)];
+                }
+                h8 f0 = hx_frag(stage, 0, 0, lane), f0l = hx_frag(stage, 0, 1, lane), f1 = hx_frag(stage, 8, 0, lane),
+                   f1l = hx_frag(stage, 8, 1, lane);
+#pragma unroll
+                for (int kc = 0; kc < 8; ++kc) {
+                    const int kn = min(kc + 1, 7);
+                    const h8 n0 = hx_frag(stage, kn, 0, lane), n0l = hx_frag(stage, kn, 1, lane), n1 = hx_frag(stage, 8 + kn, 0, lane),
+                             n1l = hx_frag(stage, 8 + kn, 1, lane);
+                    PIPE_FENCE();
+                    MFH3(f0, f0l, xh[kc], xl[kc], v[2 * half]);
+                    MFH3(f1, f1l, xh[kc], xl[kc], v[2 * half + 1]);
+                    PIPE_FENCE();
+                    f0 = n0; f0l = n0l; f1 = n1; f1l = n1l;
+                    if (half == 0 && kc == 0) fz_zt_read(rawz, zt, pl_t, h_t, 0);
+                    if (half == 0 && kc == 2) { hx_lds_done(); hx_zt_dma(rz, zt, lane_t, zsoff, zstride, znv, 1); }   // second channel half of z
+                }
+                hx_stage_landed();
+                if (half == 1) { FZ_FULL_WAIT(16); fz_zt_read(rawz, zt, pl_t, h_t, 1); FZ_FULL_WAIT(32); }
+                hx_stage_barrier();
+            }
+            float zmean, zsc;
+            {   // LayerNorm statistics of z (rawz stays as it is: it is also the residual)
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) s += (rawz[q].x + rawz[q].y) + (rawz[q].z + rawz[q].w);
+                s += __shfl_xor(s, 32);
+                zmean = s * (1.0f / 128.0f);
+                float ss = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float a = rawz[q].x - zmean, bq = rawz[q].y - zmean, c = rawz[q].z - zmean, d = rawz[q].w - zmean;
+                    ss += (a * a + bq * bq) + (c * c + d * d);
+                }
+                ss += __shfl_xor(ss, 32);
+                zsc = A.sx / sqrtf(ss * (1.0f / 128.0f) + GENIE_LN_EPS);
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {            // stages 2, 3: gates of channel blocks 2 half, 2 half + 1, then z'
+                if (half == 0) issue(3, 1);
+                else issue(4, 0);                              // first transition / projection stage
+                const unsigned char* stage = smb + half * HX_STAGE_BYTES;
+                f32x16 ga, gb;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    ga[r] = sbt[FZ_SB_BG + (2 * half) * 32 + acc_row(r, lane)];
+                    gb[r] = sbt[FZ_SB_BG + (2 * half + 1) * 32 + acc_row(r, lane)];
+                }
+                h8 f0 = hx_frag(stage, 0, 0, lane), f0l = hx_frag(stage, 0, 1, lane), f1 = hx_frag(stage, 8, 0, lane),
+                   f1l = hx_frag(stage, 8, 1, lane);
+#pragma unroll
+                for (int kc = 0; kc < 8; ++kc) {
+                    const int kn = min(kc + 1, 7);
+                    const h8 n0 = hx_frag(stage, kn, 0, lane), n0l = hx_frag(stage, kn, 1, lane), n1 = hx_frag(stage, 8 + kn, 0, lane),
+                             n1l = hx_frag(stage, 8 + kn, 1, lane);
+                    const float xz[8] = {rawz[2 * kc].x - zmean, rawz[2 * kc].y - zmean, rawz[2 * kc].z - zmean, rawz[2 * kc].w - zmean,
+                                         rawz[2 * kc + 1].x - zmean, rawz[2 * kc + 1].y - zmean, rawz[2 * kc + 1].z - zmean,
+                                         rawz[2 * kc + 1].w - zmean};
+                    h8 sh, sl;
+                    hx_split8(xz, zsc, sh, sl);
+                    PIPE_FENCE();
+                    MFH3(f0, f0l, sh, sl, ga);
+                    MFH3(f1, f1l, sh, sl, gb);
+                    PIPE_FENCE();
+                    f0 = n0; f0l = n0l; f1 = n1; f1l = n1l;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float g0 = A.cz * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ga[r] * A.cgo));
+                    const float g1 = A.cz * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gb[r] * A.cgo));
+                    // residual: channel block ob, register r <-> chunk 2 ob + (r >> 3), slot r & 7
+                    const float4 za = rawz[2 * (4 * half + (r >> 3)) + ((r & 7) >> 2)], zb = rawz[2 * (4 * half + 2 + (r >> 3)) + ((r & 7) >> 2)];
+                    const float z0 = (r & 3) == 0 ? za.x : (r & 3) == 1 ? za.y : (r & 3) == 2 ? za.z : za.w;
+                    const float z1 = (r & 3) == 0 ? zb.x : (r & 3) == 1 ? zb.y : (r & 3) == 2 ? zb.z : zb.w;
+                    v[2 * half][r] = fmaf(v[2 * half][r], g0, z0);
+                    v[2 * half + 1][r] = fmaf(v[2 * half + 1][r], g1, z1);
+                }
+                hx_stage_landed();
+                hx_stage_barrier();
+            }
+        }
+
+        h8 zh[8], zl[8];
+        // ------------------------------------------------------------------ T: z'' = (z' + W2 relu(W1 LN(z') + b1) + b2) mask
+        if constexpr (HAS_T) {
+            float mean, sc;
+            fz_stats(v, A.sx, mean, sc);
+            fz_split_tile(zh, zl, v, mean, sc);
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob)                    // the residual and b2 are the accumulators' initial value (1 / c2 is a power of two)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[ob][r] = fmaf(v[ob][r], A.inv_c2, sbt[FZ_SB_B2 + ob * 32 + acc_row(r, lane)]);
+#pragma unroll 1
+            for (int hb = 0; hb < n_hb; ++hb) {
+                issue(4 + hb + 1, (hb + 1) & 1);               // (hb = n_hb - 1: the first projection stage)
+                const unsigned char* stage = smb + (hb & 1) * HX_STAGE_BYTES;
+                f32x16 d;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d[r] = sbt[FZ_SB_B1 + hb * 32 + acc_row(r, lane)];
+                {
+                    h8 wh = hx_frag(stage, 0, 0, lane), wl = hx_frag(stage, 0, 1, lane);
+#pragma unroll
+                    for (int kc = 0; kc < 8; ++kc) {
+                        const h8 nh = hx_frag(stage, min(kc + 1, 7), 0, lane), nl = hx_frag(stage, min(kc + 1, 7), 1, lane);
+                        PIPE_FENCE();
+                        MFH3(wh, wl, zh[kc], zl[kc], d);
+                        PIPE_FENCE();
+                        wh = nh; wl = nl;
+                    }
+                }
+                h8 ah[2], al[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    float x[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = fmaxf(d[8 * c + e], 0.f);
+                    hx_split8(x, A.c1, ah[c], al[c]);
+                }
+                {
+                    h8 bh = hx_frag(stage, 8, 0, lane), bl = hx_frag(stage, 8, 1, lane);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const h8 nh = hx_frag(stage, 8 + min(u + 1, 7), 0, lane), nl = hx_frag(stage, 8 + min(u + 1, 7), 1, lane);
+                        PIPE_FENCE();
+                        MFH3(bh, bl, ah[u >> 2], al[u >> 2], v[u & 3]);
+                        PIPE_FENCE();
+                        bh = nh; bl = nl;
+                    }
+                }
+                hx_stage_landed();
+                hx_stage_barrier();
+            }
+            const float m2 = msk * A.c2;
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[ob][r] *= m2;
+        }
+
+        // ------------------------------------------------------------------ z leaves (its only write), LayerNorm for the projections
+        fz_store_half(rz, zt, v[0], v[1], lane_t, zsoff, zstride, nvalid, 0);
+        FZ_FULL_WAIT(128);
+        fz_store_half(rz, zt, v[2], v[3], lane_t, zsoff, zstride, nvalid, 1);
+        FZ_FULL_WAIT(64);
+        {
+            float mean, sc;
+            fz_stats(v, A.sx, mean, sc);
+            fz_split_tile(zh, zl, v, mean, sc);
+        }
+        hx_lds_done();                                        // the staging area is free for the next tile's z
+
+        // ------------------------------------------------------------------ P: a = (W_ap zn + b) sigmoid(W_ag zn + b) mask, b likewise
+        {
+            const float* sbias = sbt + FZ_SB_BP;
+            const float cg = A.cg;
+            const float ma = msk * A.cpa, mb = msk * A.cpb;
+            const int voff = (pl < nvalid) ? (4 * h * NP * NP + pl) * 4 : FZ_OOR;
+            const int sbase = ((b * 128 * NP + line) * NP + t0i) * 4;
+            unsigned wst[8];
+            f32x16 apA, agA, apB, agB;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { apB[r] = 0.f; agB[r] = 0.f; apA[r] = sbias[acc_row(r, lane)]; agA[r] = sbias[256 + acc_row(r, lane)]; }
+#pragma unroll 1
+            for (int pp = 0; pp < 4; ++pp) {
+                {   // even pass 2pp -> set A; epilogue of pass 2pp - 1 (set B; nothing for pp = 0: stores dropped)
+                    const int pass = 2 * pp;
+                    issue(PBASE + pass + 1, 1);
+                    const unsigned char* stage = smb;
+                    const rsrc_t e_rd = pp > 2 ? rb : ra;
+                    const int e_voff = pp == 0 ? FZ_OOR : voff;
+                    const int e_so = sbase + ((pass - 1) & 3) * 32 * sstride;
+                    const float e_pm = pp > 2 ? mb : ma;
+                    HX_PROJ_STAGE(apA, agA, apB, agB);
+                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // the next stage's weights (and what was requested a stage ago) have landed
+                    if (more && pp == 3) fz_touch_next(tile + (int)gridDim.x, 0);
+                    hx_stage_barrier();
+                }
+                {   // odd pass 2pp + 1 -> set B; epilogue of pass 2pp (set A)
+                    const int pass = 2 * pp + 1;
+                    if (pp < 3) issue(PBASE + pass + 1, 0);
+                    else if (more) issue(0, 0);
+                    const unsigned char* stage = smb + HX_STAGE_BYTES;
+                    const rsrc_t e_rd = pp < 2 ? ra : rb;
+                    const int e_voff = voff;
+                    const int e_so = sbase + ((pass - 1) & 3) * 32 * sstride;
+                    const float e_pm = pp < 2 ? ma : mb;
+                    HX_PROJ_STAGE(apB, agB, apA, agA);
+                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                    if (more && pp == 3) fz_touch_next(tile + (int)gridDim.x, 1);
+                    hx_stage_barrier();
+                }
+            }
+            {   // drain: epilogue of pass 7 (set B)
+                const rsrc_t e_rd = rb;
+                const int e_voff = voff, e_so = sbase + 3 * 32 * sstride;
+                const float e_pm = mb;
+                float t[16], u[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    HX_PROJ_PIECE_A(agB, r, t[r]);
+                    HX_PROJ_PIECE_B(apB, r, t[r], u[r]);
+                }
+                PIPE_FENCE();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) HX_PROJ_PIECE_C_NOW(r, t[r], u[r]);
+            }
+        }
+    }
+#undef FZ_XLOAD
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+static int fz_num_cu() {
+    static int n = 0;
+    if (!n) { int dev = 0; hipDeviceProp_t pr; (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&pr, dev); n = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+    return n;
+}
+
+void pair_fused_kernels_init() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_fused<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, FZ_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_fused<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FZ_LDS_BYTES);
+}
+
+// chain A of block `w` (col = true):  output of w.out (x^T in xcm) -> projections of w.in
+// chain B (col = false):              output of w.in -> transition of w -> projections of next->out
+void launch_pair_fused(genie_ctx* h, hipStream_t st, const HxFusedW& f, const HxTriW& o, const HxTransW* t, const HxTriW& p, bool col) {
+    const int N = h->N, NP = h->NP, ntile = (N + 31) / 32;
+    FusedArgs a;
+    a.z = h->p; a.xcm = h->xcm; a.rmask = h->rmaskf; a.wimg = f.img;
+    a.bzs = o.bzs; a.bgs = o.bgs; a.b1s = t ? t->b1s : nullptr; a.b2s = t ? t->b2s : nullptr; a.bproj = p.bias_proj;
+    a.acm = reinterpret_cast<unsigned*>(h->acm); a.bcm = reinterpret_cast<unsigned*>(h->bcm);
+    a.N = N; a.NP = NP; a.n_wtiles = h->B * N * ntile; a.n_hb = t ? h->d.pair_transition_n * 4 : 0;
+    a.cm_bytes = (unsigned)((size_t)h->B * 128 * NP * NP * 4);
+    a.z_bytes = (unsigned)((size_t)h->B * N * N * 512);
+    a.sx = o.sx; a.cgo = o.cgo; a.cz = o.cz;
+    a.c1 = t ? t->c1 : 0.f; a.c2 = t ? t->c2 : 1.f; a.inv_c2 = t ? 1.0f / t->c2 : 1.f;
+    a.cpa = p.cpa; a.cpb = p.cpb; a.cg = p.cg;
+    a.rev = (int)(h->hx_launches++ & 1);
+    const long long n_tiles = ((long long)a.n_wtiles + 7) / 8;
+    const unsigned grid = (unsigned)(n_tiles < fz_num_cu() ? n_tiles : fz_num_cu());
+    if (col) hipLaunchKernelGGL((k_pair_fused<true, false>), dim3(grid), dim3(512), FZ_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((k_pair_fused<false, true>), dim3(grid), dim3(512), FZ_LDS_BYTES, st, a);
+}

@@ -451,3 +451,33 @@ def test_adam_step_matches_torch_adam():
     st = opt.state[p_ref]
     assert mdiff(m, st['exp_avg']) <= 1e-6 * float(st['exp_avg'].abs().max())
     assert mdiff(v, st['exp_avg_sq']) <= 1e-6 * float(st['exp_avg_sq'].abs().max())
+
+
+def test_fused_pair_chains_match_separate_launches(base_engine, monkeypatch):
+    """The fused row-local chains (pair_fused_kernels.hip: TriMul output -> [transition ->] next projections in one kernel, z read
+    and written once per chain) against the seven separate launches per block they replace (GENIE_NO_PAIR_FUSE): same arithmetic
+    up to the order of the f32 sums.  Ragged batch, N not a multiple of 32, motif conditioning live."""
+    g = torch.Generator().manual_seed(21)
+    f = O.empty_features([70, 41, 64])
+    O.add_motif(f, 1, torch.randn(6, 3, generator=g) * 4, [3, 4, 5, 20, 21, 22])
+    B, N = f['residue_mask'].shape
+    x = torch.randn(B, N, 3, generator=g) * 4
+    base_engine.set_math('hx')
+    base_engine.bind_features(f)
+    r = base_engine.frenet(x)
+    ts = torch.tensor([900, 17, 333], dtype=torch.int32)
+    taps = ('p', 'p_layer0', 'p_trimul_out0', 's_final')
+    monkeypatch.delenv('GENIE_NO_PAIR_FUSE', raising=False)
+    a = base_engine.denoise(x, r, ts, None, taps=taps)
+    monkeypatch.setenv('GENIE_NO_PAIR_FUSE', '1')
+    b = base_engine.denoise(x, r, ts, None, taps=taps)
+    monkeypatch.delenv('GENIE_NO_PAIR_FUSE', raising=False)
+    pm = (f['residue_mask'][:, :, None] * f['residue_mask'][:, None, :]).bool()
+    for k in ('p_trimul_out0', 'p_layer0', 'p'):
+        u, w = a[k].cpu()[pm], b[k].cpu()[pm]
+        assert torch.isfinite(u).all(), k
+        assert mdiff(u, w) <= 2e-5 * max(1.0, float(w.abs().max())), k
+    m = f['residue_mask'].bool()
+    assert mdiff(a['z'].cpu()[m], b['z'].cpu()[m]) <= 2e-5 * max(1.0, float(b['z'].abs().max()))
+    # the end-of-block mask zeroes padded pairs in both forms
+    assert float(a['p'].cpu()[~pm].abs().max()) == 0.0
