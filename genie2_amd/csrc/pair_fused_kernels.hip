@@ -38,6 +38,27 @@
 #endif
 #define FZ_FULL_WAIT(bit) do { if (FZ_SAFE & (bit)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); else asm volatile("" ::: "memory"); } while (0)
 
+// developer builds (-DFZ_TS): s_memtime stamps of every wave of work-group 0, read with tests/devtools/ts_fused.py; none in the product
+#ifdef FZ_TS
+__device__ unsigned long long g_fz_ts[16][2048];      // [variant * 8 + wave]
+extern "C" int genie_fz_debug_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fz_ts), sizeof(unsigned long long) * 16 * 2048); }
+#define FZ_TS_DECL() const bool ts_on = blockIdx.x == 0; unsigned long long* ts_p = g_fz_ts[(HAS_T ? 8 : 0) + (threadIdx.x >> 6)]; int ts_n = 0
+#define FZ_STAMP() do { if (ts_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0 && ts_n < 2048) ts_p[ts_n] = t_; ++ts_n; } } while (0)
+#else
+#define FZ_TS_DECL()
+#define FZ_STAMP() do { } while (0)
+#endif
+#if defined(FZ_TS) && FZ_TS == 2
+#define FZ_STAMP2() FZ_STAMP()
+#else
+#define FZ_STAMP2() do { } while (0)
+#endif
+#if defined(FZ_TS) && FZ_TS == 3
+#define FZ_STAMP3() FZ_STAMP()
+#else
+#define FZ_STAMP3() do { } while (0)
+#endif
+
 struct FusedArgs {
     float* z; const float* xcm; const float* rmask; const unsigned char* wimg;
     const float *bzs, *bgs, *b1s, *b2s, *bproj;
@@ -45,7 +66,7 @@ struct FusedArgs {
     int N, NP, n_wtiles, n_hb;
     unsigned cm_bytes, z_bytes;
     float sx, cgo, cz, c1, c2, inv_c2, cpa, cpb, cg;
-    int rev;
+    int rev, stagger;
 };
 
 // granules (16 B = 4 channels) g and g + 2 of this lane's row: the chained-k slots e = 0..3 / 4..7 of k-chunk 4 half + q
@@ -150,22 +171,8 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
         zsoff = COL ? ((b * N + st * 32) * N + line) * 512 : ((b * N + line) * N + st * 32) * 512;
         cmoff = ((b * 128 * NP + line) * NP + st * 32) * 4;
     };
-    // L2 touch of the next tile's inputs, one dword per 128-B line: part 0 = its 128 x lines (one per channel), part 1 = the 128
-    // lines of its 32 z rows.  Two wave instructions each, nothing kept; issued in the last two projection passes.
-    auto fz_touch_next = [&](int next_tile, int part) {
-        int zs, nv, cm;
-        tile_geom(next_tile, zs, nv, cm);
-        float t0, t1;
-        if (part == 0) {
-            t0 = hx_load(rx, lane * sstride, cm);
-            t1 = hx_load(rx, (64 + lane) * sstride, cm);
-        } else {
-            const int r0 = min(lane >> 2, nv - 1), r1 = min(16 + (lane >> 2), nv - 1);
-            t0 = hx_load(rz, r0 * zstride + (lane & 3) * 128, zs);
-            t1 = hx_load(rz, r1 * zstride + (lane & 3) * 128, zs);
-        }
-        asm volatile("" :: "v"(t0), "v"(t1));
-    };
+    // (An L2 "touch" of the next tile's remaining lines -- one dword per 128-B line, 64 lines per wave instruction -- was tried
+    //  and cost 12 k cycles in the pass that waited for it: 64 lines in as many pages per instruction.)
     const int vx = (4 * h * NP * NP + pl) * 4;              // x_cm voffset: channel block of this half-wave, pair pl
     // x of chunk c: raw[2c] = channels 16c + 4h + {0..3}, raw[2c+1] = 16c + 8 + 4h + {0..3}
 #define FZ_XLOAD(c, xoff) do {                                                                                              \
@@ -175,7 +182,19 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
         raw[2 * (c) + 1].z = hx_load(rx, vx, (xoff) + (16 * (c) + 10) * sstride); raw[2 * (c) + 1].w = hx_load(rx, vx, (xoff) + (16 * (c) + 11) * sstride); \
     } while (0)
 
+    // one dword of the same image: element j (0..7) of chunk c
+    auto xld1 = [&](float4 (&raw)[16], int c, int j, int xoff) {
+        const float t = hx_load(rx, vx, xoff + (16 * c + 8 * (j >> 2) + (j & 3)) * sstride);
+        float4& d = raw[2 * c + (j >> 2)];
+        if ((j & 3) == 0) d.x = t; else if ((j & 3) == 1) d.y = t; else if ((j & 3) == 2) d.z = t; else d.w = t;
+    };
     int tile = blockIdx.x;
+    FZ_TS_DECL();
+    if (A.stagger > 0) {        // work-groups start out of phase (experiment: GENIE_FZ_STAGGER = cycles between the first and the last group of eight)
+        const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+        const long long wait = (long long)A.stagger * ((blockIdx.x >> 3) & 7) / 8;
+        while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
     issue(0, 0);
     for (int u = threadIdx.x; u < FZ_SB_FLOATS; u += 512) {
         float v = 0.f;
@@ -185,6 +204,19 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
         else if (u < FZ_SB_BP) { if (HAS_T) v = A.b2s[u - FZ_SB_B2]; }
         else v = A.bproj[u - FZ_SB_BP];
         sb[u] = v;
+    }
+    // Input prefetch, one tile ahead: the first channel half of a tile's z rows (staging area, requested behind projection passes
+    // 4 and 5) and, in chain B, the first half of its x (chunks 0..3, 32 registers, one dword behind each MFMA group of the last four
+    // transition stages -- the one phase without memory traffic of its own).  The rest is requested at the tile's start.
+    float4 raw[16];
+    {
+        int zs, nv, cm;
+        tile_geom(tile, zs, nv, cm);
+        if (HAS_T) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) FZ_XLOAD(c, cm);
+        }
+        hx_zt_dma(rz, zt, lane, zs, zstride, nv, 0);
     }
     hx_stage_landed();
     __syncthreads();
@@ -207,16 +239,16 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
         int lane_t = lane;                                    // likewise for the ~40 swizzled staging addresses derived from the lane id
         asm volatile("" : "+v"(lane_t));
         const int pl_t = lane_t & 31, h_t = lane_t >> 5;
-        // the tile's inputs: x straight into (chained-order) registers, z rows through the staging area.  Nothing of a tile is held
-        // across the previous tile's phases (registers: every phase runs at ~190-230 live values per lane); what hides the HBM
-        // latency here is the L2 touch the previous tile's projection phase made for exactly these lines (fz_touch_next).
-        float4 raw[16];
+        // the rest of the tile's x (chunks 4..7: their lines were touched into L2 by the previous tile, fz_touch_next)
+        FZ_STAMP();
 #pragma unroll
-        for (int c = 0; c < 8; ++c) FZ_XLOAD(c, cmoff);
-        hx_zt_dma(rz, zt, lane_t, zsoff, zstride, znv, 0);
+        for (int c = HAS_T ? 4 : 0; c < 8; ++c) FZ_XLOAD(c, cmoff);      // (chain A: all of x here -- no phase of it has room to fetch ahead)
         const float msk = (pl < nvalid) ? A.rmask[b * N + line] * A.rmask[b * N + t0i + pl] : 0.f;
         const bool more = tile + (int)gridDim.x < n_tiles;
+        int n_zsoff = 0, n_nv = 1, n_cmoff = 0;
+        if (more) tile_geom(tile + gridDim.x, n_zsoff, n_nv, n_cmoff);
         hx_vm_done();
+        FZ_STAMP();
         f32x16 v[4];                                          // the tile's running value: update -> z' -> (z'' accumulators) -> z''
 
         // ------------------------------------------------------------------ O: z' = z + (W_z LN(x) + b_z) sigmoid(W_g LN(z) + b_g)
@@ -224,7 +256,9 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
             h8 xh[8], xl[8];
             hx_norm_split(xh, xl, raw, A.sx);                 // (raw = x; dead from here on)
             PIPE_FENCE();
+            FZ_STAMP3();
             float4 rawz[16];
+            float zmean = 0.f, zss = 0.f;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {            // stages 0, 1: update accumulators of channel blocks 2 half, 2 half + 1
                 issue(half + 1, half ^ 1);
@@ -248,27 +282,30 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
                     f0 = n0; f0l = n0l; f1 = n1; f1l = n1l;
                     if (half == 0 && kc == 0) fz_zt_read(rawz, zt, pl_t, h_t, 0);
                     if (half == 0 && kc == 2) { hx_lds_done(); hx_zt_dma(rz, zt, lane_t, zsoff, zstride, znv, 1); }   // second channel half of z
+                    if (half == 1 && kc == 0) fz_zt_read(rawz, zt, pl_t, h_t, 1);         // (landed: stage 0 ended with vmcnt(0))
+                    // LayerNorm statistics of z between this stage's MFMAs (rawz stays as it is: it is also the residual)
+                    if (half == 1 && kc == 2) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) s += (rawz[q].x + rawz[q].y) + (rawz[q].z + rawz[q].w);
+                        s += __shfl_xor(s, 32);
+                        zmean = s * (1.0f / 128.0f);
+                    }
+                    if (half == 1 && kc >= 3 && kc <= 6) {
+#pragma unroll
+                        for (int q = 4 * (kc - 3); q < 4 * (kc - 3) + 4; ++q) {
+                            const float a = rawz[q].x - zmean, bq = rawz[q].y - zmean, c = rawz[q].z - zmean, d = rawz[q].w - zmean;
+                            zss += (a * a + bq * bq) + (c * c + d * d);
+                        }
+                    }
                 }
                 hx_stage_landed();
-                if (half == 1) { FZ_FULL_WAIT(16); fz_zt_read(rawz, zt, pl_t, h_t, 1); FZ_FULL_WAIT(32); }
                 hx_stage_barrier();
+                FZ_STAMP();
             }
-            float zmean, zsc;
-            {   // LayerNorm statistics of z (rawz stays as it is: it is also the residual)
-                float s = 0.f;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) s += (rawz[q].x + rawz[q].y) + (rawz[q].z + rawz[q].w);
-                s += __shfl_xor(s, 32);
-                zmean = s * (1.0f / 128.0f);
-                float ss = 0.f;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const float a = rawz[q].x - zmean, bq = rawz[q].y - zmean, c = rawz[q].z - zmean, d = rawz[q].w - zmean;
-                    ss += (a * a + bq * bq) + (c * c + d * d);
-                }
-                ss += __shfl_xor(ss, 32);
-                zsc = A.sx / sqrtf(ss * (1.0f / 128.0f) + GENIE_LN_EPS);
-            }
+            zss += __shfl_xor(zss, 32);
+            const float zsc = A.sx / sqrtf(zss * (1.0f / 128.0f) + GENIE_LN_EPS);
+            FZ_STAMP3();
 #pragma unroll
             for (int half = 0; half < 2; ++half) {            // stages 2, 3: gates of channel blocks 2 half, 2 half + 1, then z'
                 if (half == 0) issue(3, 1);
@@ -311,6 +348,7 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
                 }
                 hx_stage_landed();
                 hx_stage_barrier();
+                FZ_STAMP();
             }
         }
 
@@ -324,8 +362,10 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
             for (int ob = 0; ob < 4; ++ob)                    // the residual and b2 are the accumulators' initial value (1 / c2 is a power of two)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[ob][r] = fmaf(v[ob][r], A.inv_c2, sbt[FZ_SB_B2 + ob * 32 + acc_row(r, lane)]);
-#pragma unroll 1
-            for (int hb = 0; hb < n_hb; ++hb) {
+            // one hidden block; XC >= 0: the stage also requests chunk XC of the next tile's x, one dword behind each MFMA group of its
+            // first GEMM (the transition has no memory traffic of its own; a burst at a stage's end would not be overlapped)
+            auto t_stage = [&](int hb, auto xc_tag) {
+                constexpr int XC = decltype(xc_tag)::value;
                 issue(4 + hb + 1, (hb + 1) & 1);               // (hb = n_hb - 1: the first projection stage)
                 const unsigned char* stage = smb + (hb & 1) * HX_STAGE_BYTES;
                 f32x16 d;
@@ -340,6 +380,7 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
                         MFH3(wh, wl, zh[kc], zl[kc], d);
                         PIPE_FENCE();
                         wh = nh; wl = nl;
+                        if (XC >= 0 && more) xld1(raw, XC < 0 ? 0 : XC, kc, n_cmoff);
                     }
                 }
                 h8 ah[2], al[2];
@@ -361,9 +402,23 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
                         bh = nh; bl = nl;
                     }
                 }
-                hx_stage_landed();
+                if (XC >= 0 && more) {
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // everything older than this stage's 8 x loads: the next stage's weights
+                    __builtin_amdgcn_sched_barrier(0);
+                } else
+                    hx_stage_landed();
                 hx_stage_barrier();
+            };
+            const int n_plain = n_hb >= 4 ? n_hb - 4 : n_hb;
+#pragma unroll 1
+            for (int hb = 0; hb < n_plain; ++hb) t_stage(hb, std::integral_constant<int, -1>{});
+            if (n_hb >= 4) {
+                t_stage(n_hb - 4, std::integral_constant<int, 0>{});
+                t_stage(n_hb - 3, std::integral_constant<int, 1>{});
+                t_stage(n_hb - 2, std::integral_constant<int, 2>{});
+                t_stage(n_hb - 1, std::integral_constant<int, 3>{});
             }
+            FZ_STAMP();
             const float m2 = msk * A.c2;
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob)
@@ -374,14 +429,17 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
         // ------------------------------------------------------------------ z leaves (its only write), LayerNorm for the projections
         fz_store_half(rz, zt, v[0], v[1], lane_t, zsoff, zstride, nvalid, 0);
         FZ_FULL_WAIT(128);
+        FZ_STAMP3();
         fz_store_half(rz, zt, v[2], v[3], lane_t, zsoff, zstride, nvalid, 1);
         FZ_FULL_WAIT(64);
+        FZ_STAMP3();
         {
             float mean, sc;
             fz_stats(v, A.sx, mean, sc);
             fz_split_tile(zh, zl, v, mean, sc);
         }
         hx_lds_done();                                        // the staging area is free for the next tile's z
+        FZ_STAMP();
 
         // ------------------------------------------------------------------ P: a = (W_ap zn + b) sigmoid(W_ag zn + b) mask, b likewise
         {
@@ -405,9 +463,14 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
                     const int e_so = sbase + ((pass - 1) & 3) * 32 * sstride;
                     const float e_pm = pp > 2 ? mb : ma;
                     HX_PROJ_STAGE(apA, agA, apB, agB);
-                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // the next stage's weights (and what was requested a stage ago) have landed
-                    if (more && pp == 3) fz_touch_next(tile + (int)gridDim.x, 0);
+                    FZ_STAMP2();
+                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                    FZ_STAMP2();      // the next stage's weights (and what was requested a stage ago) have landed
+                    if (more) {                                // next tile: x chunks 0..3 behind passes 4, 5; z half 0 behind passes 6, 7
+                        if (pp == 2) hx_zt_dma(rz, zt, lane_t, n_zsoff, zstride, n_nv, 0, 0, 4);
+                    }
                     hx_stage_barrier();
+                    FZ_STAMP();
                 }
                 {   // odd pass 2pp + 1 -> set B; epilogue of pass 2pp (set A)
                     const int pass = 2 * pp + 1;
@@ -419,9 +482,14 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
                     const int e_so = sbase + ((pass - 1) & 3) * 32 * sstride;
                     const float e_pm = pp < 2 ? ma : mb;
                     HX_PROJ_STAGE(apB, agB, apA, agA);
+                    FZ_STAMP2();
                     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                    if (more && pp == 3) fz_touch_next(tile + (int)gridDim.x, 1);
+                    FZ_STAMP2();
+                    if (more) {
+                        if (pp == 2) hx_zt_dma(rz, zt, lane_t, n_zsoff, zstride, n_nv, 0, 4, 4);
+                    }
                     hx_stage_barrier();
+                    FZ_STAMP();
                 }
             }
             {   // drain: epilogue of pass 7 (set B)
@@ -438,6 +506,7 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) HX_PROJ_PIECE_C_NOW(r, t[r], u[r]);
             }
+            FZ_STAMP();
         }
     }
 #undef FZ_XLOAD
@@ -470,6 +539,7 @@ void launch_pair_fused(genie_ctx* h, hipStream_t st, const HxFusedW& f, const Hx
     a.c1 = t ? t->c1 : 0.f; a.c2 = t ? t->c2 : 1.f; a.inv_c2 = t ? 1.0f / t->c2 : 1.f;
     a.cpa = p.cpa; a.cpb = p.cpb; a.cg = p.cg;
     a.rev = (int)(h->hx_launches++ & 1);
+    { const char* e = getenv("GENIE_FZ_STAGGER"); a.stagger = e ? atoi(e) : 0; }
     const long long n_tiles = ((long long)a.n_wtiles + 7) / 8;
     const unsigned grid = (unsigned)(n_tiles < fz_num_cu() ? n_tiles : fz_num_cu());
     if (col) hipLaunchKernelGGL((k_pair_fused<true, false>), dim3(grid), dim3(512), FZ_LDS_BYTES, st, a);
