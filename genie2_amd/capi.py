@@ -43,6 +43,11 @@ class GenieTaps(C.Structure):
                                               'ipa_cat0')]
 
 
+class GenieTrainOpts(C.Structure):
+    _fields_ = [('tri_dropout', C.c_float), ('ipa_dropout', C.c_float), ('transition_dropout', C.c_float), ('seed', C.c_uint32),
+                ('train_mode', C.c_int32), ('fast_math', C.c_int32)]
+
+
 # name -> (restype, argtypes); every symbol include/genie_hip.h declares
 SYMBOLS = {
     'genie_create': (C.c_int, [C.POINTER(GenieDims), C.c_int, C.POINTER(C.c_void_p)]),
@@ -60,6 +65,9 @@ SYMBOLS = {
     'genie_training_loss': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     'genie_adam_step': (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
                                   C.c_double, C.c_int]),
+    'genie_train_forward_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_float, C.POINTER(GenieTrainOpts), C.c_void_p, C.c_void_p]),
+    'genie_train_workspace_bytes': (C.c_size_t, [C.c_void_p]),
     'genie_p_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p]),
     'genie_sample_loop': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

@@ -144,6 +144,28 @@ __device__ __forceinline__ void ln_rows_128(float* tile, int ld, const float* __
     }
 }
 
+
+// Quaternion of a proper rotation r (row-major 3x3): normalised column of
+// K + I with the largest diagonal (closed form of the eigenvector that
+// affine_utils.py:336-355 obtains with eigh), sign pinned by `code`.
+__device__ __forceinline__ void rot_to_quat_dev(const float* r, int code, float* q) {
+    const float xx = r[0], xy = r[1], xz = r[2], yx = r[3], yy = r[4], yz = r[5], zx = r[6], zy = r[7], zz = r[8];
+    const float d0 = 1.f + xx + yy + zz, d1 = 1.f + xx - yy - zz, d2 = 1.f + yy - xx - zz, d3 = 1.f + zz - xx - yy;
+    float c0, c1, c2, c3;
+    if (d0 >= d1 && d0 >= d2 && d0 >= d3)      { c0 = d0;      c1 = zy - yz; c2 = xz - zx; c3 = yx - xy; }
+    else if (d1 >= d2 && d1 >= d3)             { c0 = zy - yz; c1 = d1;      c2 = xy + yx; c3 = xz + zx; }
+    else if (d2 >= d3)                         { c0 = xz - zx; c1 = xy + yx; c2 = d2;      c3 = yz + zy; }
+    else                                       { c0 = yx - xy; c1 = xz + zx; c2 = yz + zy; c3 = d3; }
+    const float inv = 1.0f / sqrtf(c0 * c0 + c1 * c1 + c2 * c2 + c3 * c3);
+    q[0] = c0 * inv; q[1] = c1 * inv; q[2] = c2 * inv; q[3] = c3 * inv;
+    if (code > 0) {
+        const int m = (code - 1) >> 1;
+        const bool want_neg = ((code - 1) & 1) != 0;
+        const float comp = q[m];
+        if ((comp < 0.f) != want_neg) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    }
+}
+
 #endif  // __HIPCC__
 
 // ---------------------------------------------------------------- host side
@@ -190,8 +212,10 @@ struct StructLayerW {
 
 struct HxGemmW { const float* w; const unsigned char* img; float inv_s; };   // hx image of a k_gemm_rows weight (keyed by its f32 pack)
 
+struct genie_train_ws;
 struct genie_ctx {
     genie_dims_t d;
+    genie_train_ws* train;        // activations / scratch of the training path (genie_train.hip)
     int device;
     char err[512];
 
@@ -270,6 +294,7 @@ void launch_bb_update(genie_ctx* h, hipStream_t st, const StructLayerW& w, const
 void launch_frenet(genie_ctx* h, hipStream_t st, int mode, int step, float scale, float* trans,
                    float* rots, const float* z, const float* eps);
 void launch_fill_i32(genie_ctx* h, hipStream_t st, int32_t* p, int n, int v);
+void train_ws_free(genie_ctx* h);
 
 // profiling hooks used by the launchers
 void prof_begin(genie_ctx* h, hipStream_t st, int cls);

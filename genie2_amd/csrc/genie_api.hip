@@ -119,6 +119,7 @@ void genie_destroy(genie_handle_t h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     free_batch(h);
+    train_ws_free(h);
     if (h->wdev) (void)hipFree(h->wdev);
     if (h->hxdev) (void)hipFree(h->hxdev);
     if (h->pos_tab) (void)hipFree(h->pos_tab);

@@ -255,27 +255,6 @@ __device__ __forceinline__ void soft_bins(float* frow, float d, float dmin, floa
     }
 }
 
-// Quaternion of a proper rotation r (row-major 3x3): normalised column of
-// K + I with the largest diagonal (closed form of the eigenvector that
-// affine_utils.py:336-355 obtains with eigh), sign pinned by `code`.
-__device__ __forceinline__ void rot_to_quat_dev(const float* r, int code, float* q) {
-    const float xx = r[0], xy = r[1], xz = r[2], yx = r[3], yy = r[4], yz = r[5], zx = r[6], zy = r[7], zz = r[8];
-    const float d0 = 1.f + xx + yy + zz, d1 = 1.f + xx - yy - zz, d2 = 1.f + yy - xx - zz, d3 = 1.f + zz - xx - yy;
-    float c0, c1, c2, c3;
-    if (d0 >= d1 && d0 >= d2 && d0 >= d3)      { c0 = d0;      c1 = zy - yz; c2 = xz - zx; c3 = yx - xy; }
-    else if (d1 >= d2 && d1 >= d3)             { c0 = zy - yz; c1 = d1;      c2 = xy + yx; c3 = xz + zx; }
-    else if (d2 >= d3)                         { c0 = xz - zx; c1 = xy + yx; c2 = d2;      c3 = yz + zy; }
-    else                                       { c0 = yx - xy; c1 = xz + zx; c2 = yz + zy; c3 = d3; }
-    const float inv = 1.0f / sqrtf(c0 * c0 + c1 * c1 + c2 * c2 + c3 * c3);
-    q[0] = c0 * inv; q[1] = c1 * inv; q[2] = c2 * inv; q[3] = c3 * inv;
-    if (code > 0) {
-        const int m = (code - 1) >> 1;
-        const bool want_neg = ((code - 1) & 1) != 0;
-        const float comp = q[m];
-        if ((comp < 0.f) != want_neg) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
-    }
-}
-
 // p = (p_i + p_j + static + W_t [bins | quat | fsm | fsm]) * mask
 // (pair_feature_net.py:117-160).  static = relpos + motif term (k_pair_static).
 #define LDF 52   // 48 features + 4 pad

@@ -1,0 +1,59 @@
+// Declarations shared by the training path (train_kernels.hip: device kernels; genie_train.hip: the forward / backward sequence).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// C[z][m][n] (op)= alpha sum_k A[z][m][k] B[z][k][n] (+ bias[n]);  z = z1 * nb2 + z2, element strides throughout.
+// mode 0: store, 1: add (read-modify-write), 2: atomic add (required when nsplit > 1 or batches share C).
+struct GemmP {
+    const float* A; const float* B; float* C; const float* bias;
+    int M, N, K;
+    long long am, ak, bk, bn, cm, cn;
+    int batch, nb2;
+    long long a1, a2, b1, b2, c1, c2;
+    int nsplit; float alpha; int mode;
+};
+void launch_gemm(hipStream_t st, const GemmP& p, int terms);
+
+void launch_ln_fwd(hipStream_t st, const float* x, const float* g, const float* b, float* y, float* xhat, float* rstd, long long R, int C);
+void launch_ln_bwd(hipStream_t st, const float* dy, const float* xhat, const float* rstd, const float* g, float* dx, long long R, int C, int accumulate);
+void launch_colsum(hipStream_t st, const float* a, const float* w, long long R, int C, float* out_b, float* out_g);
+void launch_transpose(hipStream_t st, const float* in, float* out, int B, int R, int C, bool to_cm);
+void launch_pair_features(hipStream_t st, const float* trans, const float* rots, const int8_t* codes, const float* rmask, const uint8_t* fstm,
+                          const uint8_t* fsm, const float* mpos, const int32_t* ridx, const int32_t* cidx, float* F, int B, int N, int nbin,
+                          float dmin, float dstep, int relk);
+void launch_pair_sum_bwd(hipStream_t st, const float* dp, float* dpi, float* dpj, int B, int N, int C);
+
+struct IpaArgs {
+    int B, N, H, C, Pq, Pv, cp;
+    const float *q, *kv, *qp, *kp, *vp, *bias, *p, *rots, *trans, *rmask, *head_w, *wb;
+    float *att, *cat;                                   // forward outputs (kept)
+    const float* dcat;                                  // backward input
+    float *dlg, *dq, *dqp, *doptg, *dP, *dhead, *dbb, *dR, *dT, *dkv, *dkp, *dvp;
+};
+void launch_ipa_fwd(hipStream_t st, const IpaArgs& a);
+void launch_ipa_bwd(hipStream_t st, const IpaArgs& a);
+void launch_points_fwd(hipStream_t st, const float* lin, const float* rots, const float* trans, float* out0, float* out1, int M, int H, int P0, int P1);
+void launch_points_bwd(hipStream_t st, const float* lin, const float* rots, const float* dg0, const float* dg1, float* dlin, float* dR, float* dT,
+                       int M, int H, int P0, int P1);
+void launch_frames_fwd(hipStream_t st, const float* bb, const float* R, const float* T, float* R2, float* T2, int M);
+void launch_frames_bwd(hipStream_t st, const float* bb, const float* R, const float* dR2, const float* dT2, float* dbb, float* dR, float* dT, int M);
+
+// elementwise lambdas
+template <class F>
+__global__ void k_ew(long long n, F f) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) f(i);
+}
+template <class F>
+static inline void launch_ew(hipStream_t st, long long n, F f) {
+    if (n > 0) hipLaunchKernelGGL(k_ew<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, f);
+}
+// dropout keep-mask value (0 or 1 / (1 - rate)) of element `idx` of dropout site `tag`: a counter-based hash, so the forward and
+// the backward pass (and a test that rebuilds the masks in numpy) see the same mask without storing it
+__host__ __device__ static inline float drop_scale(uint32_t seed, uint32_t tag, uint64_t idx, float rate) {
+    uint32_t x = (uint32_t)idx * 0x9E3779B1u ^ (uint32_t)(idx >> 32) * 0x85EBCA77u ^ seed * 0xC2B2AE3Du ^ tag * 0x27D4EB2Fu;
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    const float u = (float)(x >> 8) * (1.0f / 16777216.0f);
+    return u < rate ? 0.f : 1.0f / (1.0f - rate);
+}

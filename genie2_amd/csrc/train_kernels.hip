@@ -1,0 +1,668 @@
+// Training path (genie/diffusion/genie.py:60-120): device kernels of the forward pass that keeps what the
+// backward pass needs, and of the hand-derived backward pass through the whole Denoiser.  Unlike the sampling path (fused,
+// fragment-packed weights) this path reads the plain state_dict blob and is built from a few general pieces:
+//   k_gemm         batched, arbitrarily strided C (+)= alpha A B (+ bias) on the bf16 matrix pipe; operands are split on the fly
+//                  into one, two or three bf16 pieces (8 / 16 / 24 significand bits, f32's exponent range: gradients of any
+//                  magnitude survive); three pieces = six MFMAs per product reproduce f32 products, one piece is the reference's
+//                  bf16 autocast;
+//                  split-K with float atomics for the tall reductions that weight gradients are
+//   k_ln_*         LayerNorm forward / backward over rows
+//   k_ew           elementwise lambdas (gates, ReLU, dropout, residuals)
+//   k_ipa_*        invariant point attention forward (keeping the attention weights) and its two backward kernels
+//   k_frames_*     BackboneUpdate / frame composition, forward and backward
+// Reference lines are cited per kernel; the derivatives are checked tensor by tensor against the reference's own autograd
+// (tests/golden/train_grads_n16_b2.npz) and against torch autograd over the oracle.
+#include <stdint.h>
+#include "common.h"
+#include "train.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ------------------------------------------------------------------------------------------------ GEMM
+template <int TERMS>
+__global__ __launch_bounds__(256) void k_gemm(const GemmP p) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[TERMS][64][40];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[TERMS][64][40];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
+    const int bz = blockIdx.z / p.nsplit, sp = blockIdx.z % p.nsplit;
+    const int z1 = bz / p.nb2, z2 = bz % p.nb2;
+    const float* A = p.A + z1 * p.a1 + z2 * p.a2;
+    const float* B = p.B + z1 * p.b1 + z2 * p.b2;
+    float* C = p.C + z1 * p.c1 + z2 * p.c2;
+    const int ks = ((p.K + p.nsplit - 1) / p.nsplit + 31) / 32 * 32;
+    const int kbeg = sp * ks, kend = min(p.K, kbeg + ks);
+    f32x16 acc = zero16();
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + 256 * q;
+            {
+                int kk, mm;
+                if (p.ak == 1) { kk = e & 31; mm = e >> 5; } else { mm = e & 63; kk = e >> 6; }
+                const float v = (m0 + mm < p.M && k0 + kk < kend) ? A[(long long)(m0 + mm) * p.am + (long long)(k0 + kk) * p.ak] : 0.f;
+                const __bf16 hi = (__bf16)v;
+                As[0][mm][kk] = hi;
+                if (TERMS > 1) {
+                    const float r1 = v - (float)hi;
+                    const __bf16 mid = (__bf16)r1;
+                    As[1][mm][kk] = mid;
+                    if (TERMS > 2) As[2][mm][kk] = (__bf16)(r1 - (float)mid);
+                }
+            }
+            {
+                int kk, nn;
+                if (p.bk == 1) { kk = e & 31; nn = e >> 5; } else { nn = e & 63; kk = e >> 6; }
+                const float v = (n0 + nn < p.N && k0 + kk < kend) ? B[(long long)(k0 + kk) * p.bk + (long long)(n0 + nn) * p.bn] : 0.f;
+                const __bf16 hi = (__bf16)v;
+                Bs[0][nn][kk] = hi;
+                if (TERMS > 1) {
+                    const float r1 = v - (float)hi;
+                    const __bf16 mid = (__bf16)r1;
+                    Bs[1][nn][kk] = mid;
+                    if (TERMS > 2) Bs[2][nn][kk] = (__bf16)(r1 - (float)mid);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ko = c * 16 + 8 * (lane >> 5);
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&As[0][wm * 32 + (lane & 31)][ko]);
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bs[0][wn * 32 + (lane & 31)][ko]);
+            if (TERMS > 1) {     // small terms first
+                const bf16x8 am = *reinterpret_cast<const bf16x8*>(&As[1][wm * 32 + (lane & 31)][ko]);
+                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(&Bs[1][wn * 32 + (lane & 31)][ko]);
+                if (TERMS > 2) {
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&As[2][wm * 32 + (lane & 31)][ko]);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bs[2][wn * 32 + (lane & 31)][ko]);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col >= p.N) return;
+    const float bv = (p.bias && sp == 0) ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + acc_row(r, lane);
+        if (row >= p.M) continue;
+        float* d = C + (long long)row * p.cm + (long long)col * p.cn;
+        const float t = acc[r];
+        const float v = t * p.alpha + bv;
+        if (p.mode == 0) *d = v;
+        else if (p.mode == 1) *d += v;
+        else atomicAdd(d, v);
+    }
+}
+
+// terms: bf16 pieces per operand -- 1: plain bf16 (one MFMA per product), 2: 16 significand bits (three MFMAs), 3: 24 bits (six)
+void launch_gemm(hipStream_t st, const GemmP& p, int terms) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.batch <= 0) return;
+    const dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, p.batch * p.nsplit);
+    if (terms <= 1) hipLaunchKernelGGL(k_gemm<1>, grid, dim3(256), 0, st, p);
+    else if (terms == 2) hipLaunchKernelGGL(k_gemm<2>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(k_gemm<3>, grid, dim3(256), 0, st, p);
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm (eps 1e-5, affine)
+// one wave per row, C <= 512; keeps xhat and 1/sigma
+__global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                float* __restrict__ y, float* __restrict__ xhat, float* __restrict__ rstd, long long R, int C) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const float* xr = x + row * C;
+    float v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int c = lane + 64 * q; v[q] = c < C ? xr[c] : 0.f; s += v[q]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int c = lane + 64 * q; const float d = c < C ? v[q] - mean : 0.f; ss += d * d; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float rs = 1.0f / sqrtf(ss / (float)C + GENIE_LN_EPS);
+    if (lane == 0 && rstd) rstd[row] = rs;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = lane + 64 * q;
+        if (c < C) {
+            const float xh = (v[q] - mean) * rs;
+            if (xhat) xhat[row * C + c] = xh;
+            y[row * C + c] = xh * g[c] + b[c];
+        }
+    }
+}
+// dx = rstd (dy g - mean(dy g) - xhat mean(dy g xhat)); `accumulate`: dx += (residual path already holds a gradient)
+__global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ rstd,
+                                                const float* __restrict__ g, float* __restrict__ dx, long long R, int C, int accumulate) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= R) return;
+    float t[8], xh[8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = lane + 64 * q;
+        t[q] = c < C ? dy[row * C + c] * g[c] : 0.f;
+        xh[q] = c < C ? xhat[row * C + c] : 0.f;
+        s1 += t[q]; s2 += t[q] * xh[q];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    s1 /= (float)C; s2 /= (float)C;
+    const float rs = rstd[row];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = lane + 64 * q;
+        if (c < C) {
+            const float v = rs * (t[q] - s1 - xh[q] * s2);
+            if (accumulate) dx[row * C + c] += v; else dx[row * C + c] = v;
+        }
+    }
+}
+// column sums over rows: out_b[c] += sum_r a[r,c];  out_g[c] += sum_r a[r,c] w[r,c]   (LayerNorm gamma / beta and Linear bias gradients)
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ a, const float* __restrict__ w, long long R, int C, int rows_per_block,
+                                                float* __restrict__ out_b, float* __restrict__ out_g) {
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float sb = 0.f, sg = 0.f;
+        for (long long r = r0; r < r1; ++r) {
+            const float v = a[r * C + c];
+            sb += v;
+            if (w) sg += v * w[r * C + c];
+        }
+        if (out_b) atomicAdd(out_b + c, sb);
+        if (out_g) atomicAdd(out_g + c, sg);
+    }
+}
+void launch_ln_fwd(hipStream_t st, const float* x, const float* g, const float* b, float* y, float* xhat, float* rstd, long long R, int C) {
+    hipLaunchKernelGGL(k_ln_fwd, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, x, g, b, y, xhat, rstd, R, C);
+}
+void launch_ln_bwd(hipStream_t st, const float* dy, const float* xhat, const float* rstd, const float* g, float* dx, long long R, int C, int accumulate) {
+    hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, dy, xhat, rstd, g, dx, R, C, accumulate);
+}
+void launch_colsum(hipStream_t st, const float* a, const float* w, long long R, int C, float* out_b, float* out_g) {
+    const int rpb = 256;
+    hipLaunchKernelGGL(k_colsum, dim3((unsigned)((R + rpb - 1) / rpb)), dim3(256), 0, st, a, w, R, C, rpb, out_b, out_g);
+}
+
+// ------------------------------------------------------------------------------------------------ [B][R][C] <-> [B][C][R]
+__global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ in, float* __restrict__ out, int R, int C, int to_cm) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    const float* src = in + (size_t)b * R * C;
+    float* dst = out + (size_t)b * R * C;
+    if (to_cm) {        // in [R][C] -> out [C][R]
+        for (int q = ty; q < 32; q += 8) tile[q][tx] = (r0 + q < R && c0 + tx < C) ? src[(size_t)(r0 + q) * C + c0 + tx] : 0.f;
+        __syncthreads();
+        for (int q = ty; q < 32; q += 8) if (c0 + q < C && r0 + tx < R) dst[(size_t)(c0 + q) * R + r0 + tx] = tile[tx][q];
+    } else {            // in [C][R] -> out [R][C]
+        for (int q = ty; q < 32; q += 8) tile[q][tx] = (c0 + q < C && r0 + tx < R) ? src[(size_t)(c0 + q) * R + r0 + tx] : 0.f;
+        __syncthreads();
+        for (int q = ty; q < 32; q += 8) if (r0 + q < R && c0 + tx < C) dst[(size_t)(r0 + q) * C + c0 + tx] = tile[tx][q];
+    }
+}
+void launch_transpose(hipStream_t st, const float* in, float* out, int B, int R, int C, bool to_cm) {
+    hipLaunchKernelGGL(k_transpose, dim3((R + 31) / 32, (C + 31) / 32, B), dim3(256), 0, st, in, out, R, C, to_cm ? 1 : 0);
+}
+
+// ------------------------------------------------------------------------------------------------ pair features (pair_feature_net.py:117-301)
+// F[p] = [ template: nbin soft bins | 4 quat | fsm | fsm ] [ motif: nbin bins * fsm | fsm | fsm ] [ relpos one-hot (2k+2) | same chain ]
+// one thread per pair (b, i, j); the same closed-form quaternion and sign codes as the sampling path (common.h)
+__global__ __launch_bounds__(256) void k_pair_features(const float* __restrict__ trans, const float* __restrict__ rots, const int8_t* __restrict__ codes,
+                                                       const float* __restrict__ rmask, const uint8_t* __restrict__ fstm, const uint8_t* __restrict__ fsm,
+                                                       const float* __restrict__ mpos, const int32_t* __restrict__ ridx, const int32_t* __restrict__ cidx,
+                                                       float* __restrict__ F, int B, int N, int nbin, float dmin, float dstep, int relk) {
+    const long long pidx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (pidx >= (long long)B * N * N) return;
+    const int j = (int)(pidx % N), i = (int)((pidx / N) % N), b = (int)(pidx / ((long long)N * N));
+    const int nf = (nbin + 6) + (nbin + 2) + (2 * relk + 3);
+    float* f = F + pidx * nf;
+    const float pm = rmask[b * N + i] * rmask[b * N + j];
+    const float fs = fstm[pidx] ? 1.f : 0.f;
+    auto bins = [&](const float* xi, const float* xj, float scale, float* out) {
+        const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
+        const float d = sqrtf(1e-10f + dx * dx + dy * dy + dz * dz);
+        float mx = -3.0e38f;
+        for (int k = 0; k < nbin; ++k) mx = fmaxf(mx, -4.0f * fabsf(d - (dmin + (float)k * dstep)));
+        float s = 0.f;
+        for (int k = 0; k < nbin; ++k) { const float e = expf(-4.0f * fabsf(d - (dmin + (float)k * dstep)) - mx); out[k] = e; s += e; }
+        const float inv = scale / s;
+        for (int k = 0; k < nbin; ++k) out[k] *= inv;
+    };
+    bins(trans + (size_t)(b * N + i) * 3, trans + (size_t)(b * N + j) * 3, pm, f);
+    {   // r = R_j R_i (pair_feature_net.py:288-291), quaternion * pair mask
+        const float* Ri = rots + (size_t)(b * N + i) * 9;
+        const float* Rj = rots + (size_t)(b * N + j) * 9;
+        float r[9];
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) r[a * 3 + c] = Rj[a * 3] * Ri[c] + Rj[a * 3 + 1] * Ri[3 + c] + Rj[a * 3 + 2] * Ri[6 + c];
+        float q[4];
+        rot_to_quat_dev(r, codes ? (int)codes[pidx] : 0, q);
+        for (int a = 0; a < 4; ++a) f[nbin + a] = q[a] * pm;
+        f[nbin + 4] = fs; f[nbin + 5] = fs;
+    }
+    float* fm = f + nbin + 6;
+    {   // motif template: bins of the motif coordinates under the fixed-sequence pair mask, times the fixed-structure mask
+        const float mm = (fsm[b * N + i] ? 1.f : 0.f) * (fsm[b * N + j] ? 1.f : 0.f);
+        bins(mpos + (size_t)(b * N + i) * 3, mpos + (size_t)(b * N + j) * 3, mm * fs, fm);
+        fm[nbin] = fs; fm[nbin + 1] = fs;
+    }
+    float* fr = fm + nbin + 2;
+    {
+        const bool same = cidx[b * N + i] == cidx[b * N + j];
+        int d = ridx[b * N + i] - ridx[b * N + j] + relk;
+        d = d < 0 ? 0 : (d > 2 * relk ? 2 * relk : d);
+        const int sel = same ? d : 2 * relk + 1;
+        for (int k = 0; k < 2 * relk + 2; ++k) fr[k] = k == sel ? 1.f : 0.f;
+        fr[2 * relk + 2] = same ? 1.f : 0.f;
+    }
+}
+void launch_pair_features(hipStream_t st, const float* trans, const float* rots, const int8_t* codes, const float* rmask, const uint8_t* fstm,
+                          const uint8_t* fsm, const float* mpos, const int32_t* ridx, const int32_t* cidx, float* F, int B, int N, int nbin,
+                          float dmin, float dstep, int relk) {
+    const long long P = (long long)B * N * N;
+    hipLaunchKernelGGL(k_pair_features, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, trans, rots, codes, rmask, fstm, fsm, mpos, ridx, cidx,
+                       F, B, N, nbin, dmin, dstep, relk);
+}
+// p[b,i,j,:] = (p[b,i,j,:] + pi[b,i,:] + pj[b,j,:]) * mask   and its transpose: dpi[b,i,:] = sum_j dp, dpj[b,j,:] = sum_i dp
+__global__ __launch_bounds__(128) void k_pair_sum_bwd(const float* __restrict__ dp, float* __restrict__ dpi, float* __restrict__ dpj, int N, int C) {
+    const int bi = blockIdx.x;                  // (b, i): row sum over j -> dpi[b, i]; and column role: (b, j = i) sum over rows
+    const int b = bi / N, i = bi % N;
+    for (int c = threadIdx.x; c < C; c += 128) {
+        float s = 0.f, t = 0.f;
+        for (int j = 0; j < N; ++j) {
+            s += dp[((size_t)bi * N + j) * C + c];
+            t += dp[(((size_t)b * N + j) * N + i) * C + c];
+        }
+        dpi[(size_t)bi * C + c] = s;
+        dpj[(size_t)bi * C + c] = t;
+    }
+}
+void launch_pair_sum_bwd(hipStream_t st, const float* dp, float* dpi, float* dpj, int B, int N, int C) {
+    hipLaunchKernelGGL(k_pair_sum_bwd, dim3(B * N), dim3(128), 0, st, dp, dpi, dpj, N, C);
+}
+
+// ------------------------------------------------------------------------------------------------ invariant point attention
+// (modules/invariant_point_attention.py:100-260).  Row-major inputs straight from the projection GEMMs:
+//   q [M][H C], kv [M][H][2C] (k, then v), global-frame points qp [M][H][Pq][3], kp [M][H][Pq][3], vp [M][H][Pv][3],
+//   bias [B N N][H] = linear_b(p), p [B N N][cp].  One work-group per query (b, i).
+struct IpaDims { int B, N, H, C, Pq, Pv, cp; float c_qk, c_b; };
+__device__ __forceinline__ float softplus_dev(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+__global__ __launch_bounds__(256) void k_ipa_fwd(IpaDims d, const float* __restrict__ q, const float* __restrict__ kv, const float* __restrict__ qp,
+                                                 const float* __restrict__ kp, const float* __restrict__ vp, const float* __restrict__ bias,
+                                                 const float* __restrict__ p, const float* __restrict__ rots, const float* __restrict__ trans,
+                                                 const float* __restrict__ rmask, const float* __restrict__ head_w, float* __restrict__ att_out,
+                                                 float* __restrict__ cat) {
+    extern __shared__ float sm[];
+    const int N = d.N, H = d.H, C = d.C, Pq = d.Pq, Pv = d.Pv, cp = d.cp;
+    float* att = sm;                        // [H][N]
+    float* sq = att + H * N;                // [H C]
+    float* sqp = sq + H * C;                // [H Pq 3]
+    float* sopt = sqp + H * Pq * 3;         // [H Pv 3] global-frame output points
+    const int bi = blockIdx.x, b = bi / N, i = bi % N, tid = threadIdx.x;
+    for (int u = tid; u < H * C; u += 256) sq[u] = q[(size_t)bi * H * C + u];
+    for (int u = tid; u < H * Pq * 3; u += 256) sqp[u] = qp[(size_t)bi * H * Pq * 3 + u];
+    __syncthreads();
+    const float mi = rmask[bi];
+    const float cpt = sqrtf(1.0f / (3.0f * ((float)Pq * 9.0f / 2.0f)));
+    for (int u = tid; u < H * N; u += 256) {
+        const int h = u / N, j = u % N;
+        const size_t mj = (size_t)b * N + j;
+        const float* kr = kv + (mj * H + h) * 2 * C;
+        float a = 0.f;
+        for (int c = 0; c < C; ++c) a += sq[h * C + c] * kr[c];
+        a = a * d.c_qk + d.c_b * bias[((size_t)bi * N + j) * H + h];
+        float ds = 0.f;
+        const float* kpr = kp + (mj * H + h) * Pq * 3;
+        for (int t = 0; t < Pq * 3; ++t) { const float df = sqp[h * Pq * 3 + t] - kpr[t]; ds += df * df; }
+        a += -0.5f * softplus_dev(head_w[h]) * cpt * ds + 1e5f * (mi * rmask[mj] - 1.0f);
+        att[u] = a;
+    }
+    __syncthreads();
+    {   // softmax over j, one wave per head at a time
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int h = wave; h < H; h += 4) {
+            float mx = -3.0e38f;
+            for (int j = lane; j < N; j += 64) mx = fmaxf(mx, att[h * N + j]);
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            float s = 0.f;
+            for (int j = lane; j < N; j += 64) { const float e = expf(att[h * N + j] - mx); att[h * N + j] = e; s += e; }
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            const float inv = 1.0f / s;
+            for (int j = lane; j < N; j += 64) { const float a = att[h * N + j] * inv; att[h * N + j] = a; att_out[(((size_t)b * H + h) * N + i) * N + j] = a; }
+        }
+    }
+    __syncthreads();
+    const int ncat = H * (C + 4 * Pv + cp);
+    float* crow = cat + (size_t)bi * ncat;
+    for (int u = tid; u < H * C; u += 256) {          // o
+        const int h = u / C, c = u % C;
+        float s = 0.f;
+        for (int j = 0; j < N; ++j) s += att[h * N + j] * kv[(((size_t)b * N + j) * H + h) * 2 * C + C + c];
+        crow[u] = s;
+    }
+    for (int u = tid; u < H * Pv * 3; u += 256) {     // o_pt, global frame
+        const int h = u / (Pv * 3), t = u % (Pv * 3);
+        float s = 0.f;
+        for (int j = 0; j < N; ++j) s += att[h * N + j] * vp[(((size_t)b * N + j) * H + h) * Pv * 3 + t];
+        sopt[u] = s;
+    }
+    for (int u = tid; u < H * cp; u += 256) {         // o_pair
+        const int h = u / cp, c = u % cp;
+        float s = 0.f;
+        for (int j = 0; j < N; ++j) s += att[h * N + j] * p[((size_t)bi * N + j) * cp + c];
+        crow[H * C + 4 * H * Pv + u] = s;
+    }
+    __syncthreads();
+    const float* R = rots + (size_t)bi * 9;
+    const float* T = trans + (size_t)bi * 3;
+    for (int u = tid; u < H * Pv; u += 256) {         // local frame: R^T (g - t), and its norm
+        const float w0 = sopt[u * 3] - T[0], w1 = sopt[u * 3 + 1] - T[1], w2 = sopt[u * 3 + 2] - T[2];
+        const float l0 = R[0] * w0 + R[3] * w1 + R[6] * w2, l1 = R[1] * w0 + R[4] * w1 + R[7] * w2, l2 = R[2] * w0 + R[5] * w1 + R[8] * w2;
+        crow[H * C + u] = l0; crow[H * C + H * Pv + u] = l1; crow[H * C + 2 * H * Pv + u] = l2;
+        crow[H * C + 3 * H * Pv + u] = sqrtf(l0 * l0 + l1 * l1 + l2 * l2 + 1e-8f);
+    }
+}
+
+// backward, per query (b, i): d logits (kept for the per-key kernel and the linear_b gradient), dq, dq_pts (global), the pair
+// gradient rows (b, i, :, :), d head_weights, the query's own frame gradient from the output points
+__global__ __launch_bounds__(256) void k_ipa_bwd_q(IpaDims d, const float* __restrict__ q, const float* __restrict__ kv, const float* __restrict__ qp,
+                                                   const float* __restrict__ kp, const float* __restrict__ vp, const float* __restrict__ p,
+                                                   const float* __restrict__ rots, const float* __restrict__ trans, const float* __restrict__ head_w,
+                                                   const float* __restrict__ wb, const float* __restrict__ att_in, const float* __restrict__ cat,
+                                                   const float* __restrict__ dcat, float* __restrict__ dlg, float* __restrict__ dq, float* __restrict__ dqp,
+                                                   float* __restrict__ doptg, float* __restrict__ dP, float* __restrict__ dhead, float* __restrict__ dbb,
+                                                   float* __restrict__ dR, float* __restrict__ dT) {
+    extern __shared__ float sm[];
+    const int N = d.N, H = d.H, C = d.C, Pq = d.Pq, Pv = d.Pv, cp = d.cp;
+    float* att = sm;                        // [H][N]
+    float* dat = att + H * N;               // [H][N] d att -> d logits
+    float* sdo = dat + H * N;               // [H C]
+    float* sdg = sdo + H * C;               // [H Pv 3] d o_pt (global)
+    float* sdop = sdg + H * Pv * 3;         // [H cp] d o_pair
+    float* sqp = sdop + H * cp;             // [H Pq 3]
+    float* sq = sqp + H * Pq * 3;           // [H C]
+    float* red = sq + H * C;                // [16] scratch: frame gradient (9 + 3)
+    const int bi = blockIdx.x, b = bi / N, i = bi % N, tid = threadIdx.x;
+    const int ncat = H * (C + 4 * Pv + cp);
+    const float* crow = cat + (size_t)bi * ncat;
+    const float* drow = dcat + (size_t)bi * ncat;
+    const float* R = rots + (size_t)bi * 9;
+    if (tid < 16) red[tid] = 0.f;
+    for (int u = tid; u < H * N; u += 256) { const int h = u / N, j = u % N; att[u] = att_in[(((size_t)b * H + h) * N + i) * N + j]; }
+    for (int u = tid; u < H * C; u += 256) { sdo[u] = drow[u]; sq[u] = q[(size_t)bi * H * C + u]; }
+    for (int u = tid; u < H * cp; u += 256) sdop[u] = drow[H * C + 4 * H * Pv + u];
+    for (int u = tid; u < H * Pq * 3; u += 256) sqp[u] = qp[(size_t)bi * H * Pq * 3 + u];
+    __syncthreads();
+    for (int u = tid; u < H * Pv; u += 256) {         // through norm and local frame: l = R^T w, w = g - t
+        const float l0 = crow[H * C + u], l1 = crow[H * C + H * Pv + u], l2 = crow[H * C + 2 * H * Pv + u], nr = crow[H * C + 3 * H * Pv + u];
+        const float dn = drow[H * C + 3 * H * Pv + u] / nr;
+        const float g0 = drow[H * C + u] + dn * l0, g1 = drow[H * C + H * Pv + u] + dn * l1, g2 = drow[H * C + 2 * H * Pv + u] + dn * l2;
+        // d w = R d l
+        const float w0 = R[0] * g0 + R[1] * g1 + R[2] * g2, w1 = R[3] * g0 + R[4] * g1 + R[5] * g2, w2 = R[6] * g0 + R[7] * g1 + R[8] * g2;
+        sdg[u * 3] = w0; sdg[u * 3 + 1] = w1; sdg[u * 3 + 2] = w2;
+        doptg[((size_t)bi * H * Pv + u) * 3] = w0; doptg[((size_t)bi * H * Pv + u) * 3 + 1] = w1; doptg[((size_t)bi * H * Pv + u) * 3 + 2] = w2;
+        // dR[a][c] += w_a dl_c with w = R l;  dt -= d w
+        const float x0 = R[0] * l0 + R[1] * l1 + R[2] * l2, x1 = R[3] * l0 + R[4] * l1 + R[5] * l2, x2 = R[6] * l0 + R[7] * l1 + R[8] * l2;
+        atomicAdd(red + 0, x0 * g0); atomicAdd(red + 1, x0 * g1); atomicAdd(red + 2, x0 * g2);
+        atomicAdd(red + 3, x1 * g0); atomicAdd(red + 4, x1 * g1); atomicAdd(red + 5, x1 * g2);
+        atomicAdd(red + 6, x2 * g0); atomicAdd(red + 7, x2 * g1); atomicAdd(red + 8, x2 * g2);
+        atomicAdd(red + 9, -w0); atomicAdd(red + 10, -w1); atomicAdd(red + 11, -w2);
+    }
+    __syncthreads();
+    if (tid < 9) dR[(size_t)bi * 9 + tid] += red[tid];
+    else if (tid < 12) dT[(size_t)bi * 3 + tid - 9] += red[tid];
+    for (int u = tid; u < H * N; u += 256) {          // d att
+        const int h = u / N, j = u % N;
+        const size_t mj = (size_t)b * N + j;
+        float s = 0.f;
+        const float* vr = kv + (mj * H + h) * 2 * C + C;
+        for (int c = 0; c < C; ++c) s += sdo[h * C + c] * vr[c];
+        const float* vpr = vp + (mj * H + h) * Pv * 3;
+        for (int t = 0; t < Pv * 3; ++t) s += sdg[h * Pv * 3 + t] * vpr[t];
+        const float* pr = p + ((size_t)bi * N + j) * cp;
+        for (int c = 0; c < cp; ++c) s += sdop[h * cp + c] * pr[c];
+        dat[u] = s;
+    }
+    __syncthreads();
+    const float cpt = sqrtf(1.0f / (3.0f * ((float)Pq * 9.0f / 2.0f)));
+    {   // d logits = att (d att - sum_j att d att); d head_weights, d bias of linear_b
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int h = wave; h < H; h += 4) {
+            float s = 0.f;
+            for (int j = lane; j < N; j += 64) s += att[h * N + j] * dat[h * N + j];
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            float sb = 0.f, sh = 0.f;
+            for (int j = lane; j < N; j += 64) {
+                const float g = att[h * N + j] * (dat[h * N + j] - s);
+                dat[h * N + j] = g;
+                dlg[(((size_t)b * H + h) * N + i) * N + j] = g;
+                sb += g;
+                float ds = 0.f;
+                const float* kpr = kp + (((size_t)b * N + j) * H + h) * Pq * 3;
+                for (int t = 0; t < Pq * 3; ++t) { const float df = sqp[h * Pq * 3 + t] - kpr[t]; ds += df * df; }
+                sh += g * ds;
+            }
+            for (int o = 32; o > 0; o >>= 1) { sb += __shfl_xor(sb, o); sh += __shfl_xor(sh, o); }
+            if (lane == 0) {
+                atomicAdd(dbb + h, d.c_b * sb);
+                const float hw = head_w[h];
+                atomicAdd(dhead + h, -0.5f * cpt * sh / (1.0f + expf(-hw)));          // d softplus = sigmoid
+            }
+        }
+    }
+    __syncthreads();
+    for (int u = tid; u < H * C; u += 256) {          // dq
+        const int h = u / C, c = u % C;
+        float s = 0.f;
+        for (int j = 0; j < N; ++j) s += dat[h * N + j] * kv[(((size_t)b * N + j) * H + h) * 2 * C + c];
+        dq[(size_t)bi * H * C + u] = s * d.c_qk;
+    }
+    for (int u = tid; u < H * Pq * 3; u += 256) {     // dq_pts (global): -hw sum_j dlogit (qp - kp_j)
+        const int h = u / (Pq * 3), t = u % (Pq * 3);
+        float s = 0.f;
+        for (int j = 0; j < N; ++j) s += dat[h * N + j] * (sqp[u] - kp[(((size_t)b * N + j) * H + h) * Pq * 3 + t]);
+        dqp[(size_t)bi * H * Pq * 3 + u] = -softplus_dev(head_w[h]) * cpt * s;
+    }
+    for (int c = tid; c < cp; c += 256) {             // pair gradient rows (b, i, j, :) += sum_h att do_pair + c_b dlogit W_b
+        for (int j = 0; j < N; ++j) {
+            float s = 0.f;
+            for (int h = 0; h < H; ++h) s += att[h * N + j] * sdop[h * cp + c] + d.c_b * dat[h * N + j] * wb[h * cp + c];
+            dP[((size_t)bi * N + j) * cp + c] += s;
+        }
+    }
+}
+// backward, per key (b, j): dk, dv (into dkv), dk_pts, dv_pts (global)
+__global__ __launch_bounds__(256) void k_ipa_bwd_k(IpaDims d, const float* __restrict__ q, const float* __restrict__ qp, const float* __restrict__ kp,
+                                                   const float* __restrict__ head_w, const float* __restrict__ att_in, const float* __restrict__ dlg,
+                                                   const float* __restrict__ dcat, const float* __restrict__ doptg, float* __restrict__ dkv,
+                                                   float* __restrict__ dkp, float* __restrict__ dvp) {
+    extern __shared__ float sm[];
+    const int N = d.N, H = d.H, C = d.C, Pq = d.Pq, Pv = d.Pv, cp = d.cp;
+    float* att = sm;                // [H][N] over queries i
+    float* dl = att + H * N;        // [H][N]
+    const int bj = blockIdx.x, b = bj / N, j = bj % N, tid = threadIdx.x;
+    const int ncat = H * (C + 4 * Pv + cp);
+    for (int u = tid; u < H * N; u += 256) {
+        const int h = u / N, i = u % N;
+        att[u] = att_in[(((size_t)b * H + h) * N + i) * N + j];
+        dl[u] = dlg[(((size_t)b * H + h) * N + i) * N + j];
+    }
+    __syncthreads();
+    const float cpt = sqrtf(1.0f / (3.0f * ((float)Pq * 9.0f / 2.0f)));
+    for (int u = tid; u < H * C; u += 256) {
+        const int h = u / C, c = u % C;
+        float sk = 0.f, sv = 0.f;
+        for (int i = 0; i < N; ++i) {
+            const size_t mi = (size_t)b * N + i;
+            sk += dl[h * N + i] * q[mi * H * C + u];
+            sv += att[h * N + i] * dcat[mi * ncat + u];
+        }
+        dkv[((size_t)bj * H + h) * 2 * C + c] = sk * d.c_qk;
+        dkv[((size_t)bj * H + h) * 2 * C + C + c] = sv;
+    }
+    for (int u = tid; u < H * Pq * 3; u += 256) {
+        const int h = u / (Pq * 3);
+        float s = 0.f;
+        const float kpv = kp[(size_t)bj * H * Pq * 3 + u];
+        for (int i = 0; i < N; ++i) s += dl[h * N + i] * (qp[((size_t)b * N + i) * H * Pq * 3 + u] - kpv);
+        dkp[(size_t)bj * H * Pq * 3 + u] = softplus_dev(head_w[h]) * cpt * s;
+    }
+    for (int u = tid; u < H * Pv * 3; u += 256) {
+        const int h = u / (Pv * 3);
+        float s = 0.f;
+        for (int i = 0; i < N; ++i) s += att[h * N + i] * doptg[((size_t)b * N + i) * H * Pv * 3 + u];
+        dvp[(size_t)bj * H * Pv * 3 + u] = s;
+    }
+}
+size_t ipa_train_lds(int N, int H, int C, int Pq, int Pv, int cp) {
+    return (size_t)(2 * H * N + 2 * H * C + H * Pv * 3 + H * cp + H * Pq * 3 + 16) * sizeof(float);
+}
+void launch_ipa_fwd(hipStream_t st, const IpaArgs& a) {
+    IpaDims d{a.B, a.N, a.H, a.C, a.Pq, a.Pv, a.cp, sqrtf(1.0f / (3.0f * a.C)), sqrtf(1.0f / 3.0f)};
+    const size_t lds = ipa_train_lds(a.N, a.H, a.C, a.Pq, a.Pv, a.cp);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_ipa_fwd, dim3(a.B * a.N), dim3(256), lds, st, d, a.q, a.kv, a.qp, a.kp, a.vp, a.bias, a.p, a.rots, a.trans, a.rmask,
+                       a.head_w, a.att, a.cat);
+}
+void launch_ipa_bwd(hipStream_t st, const IpaArgs& a) {
+    IpaDims d{a.B, a.N, a.H, a.C, a.Pq, a.Pv, a.cp, sqrtf(1.0f / (3.0f * a.C)), sqrtf(1.0f / 3.0f)};
+    const size_t lds = ipa_train_lds(a.N, a.H, a.C, a.Pq, a.Pv, a.cp);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_bwd_q), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_bwd_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_ipa_bwd_q, dim3(a.B * a.N), dim3(256), lds, st, d, a.q, a.kv, a.qp, a.kp, a.vp, a.p, a.rots, a.trans, a.head_w, a.wb,
+                       a.att, a.cat, a.dcat, a.dlg, a.dq, a.dqp, a.doptg, a.dP, a.dhead, a.dbb, a.dR, a.dT);
+    hipLaunchKernelGGL(k_ipa_bwd_k, dim3(a.B * a.N), dim3(256), lds, st, d, a.q, a.qp, a.kp, a.head_w, a.att, a.dlg, a.dcat, a.doptg, a.dkv,
+                       a.dkp, a.dvp);
+}
+
+// ------------------------------------------------------------------------------------------------ points and frames
+// linear output [M][3 H P] = [x block | y block | z block]  <->  global-frame points [M][H][P][3] = R l + t
+// (invariant_point_attention.py:137-174); `kvsplit`: the kv points' (Pq + Pv) are split into k points and v points
+__global__ void k_points_fwd(const float* __restrict__ lin, const float* __restrict__ rots, const float* __restrict__ trans, float* __restrict__ out0,
+                             float* __restrict__ out1, int M, int H, int P0, int P1) {
+    const int PT = P0 + P1;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)M * H * PT) return;
+    const int pt = (int)(idx % PT), h = (int)((idx / PT) % H);
+    const long long m = idx / ((long long)PT * H);
+    const float* l = lin + m * 3 * H * PT + h * PT + pt;
+    const float l0 = l[0], l1 = l[H * PT], l2 = l[2 * H * PT];
+    const float* R = rots + m * 9;
+    const float* T = trans + m * 3;
+    const float g0 = R[0] * l0 + R[1] * l1 + R[2] * l2 + T[0], g1 = R[3] * l0 + R[4] * l1 + R[5] * l2 + T[1], g2 = R[6] * l0 + R[7] * l1 + R[8] * l2 + T[2];
+    float* o = pt < P0 ? out0 + ((m * H + h) * P0 + pt) * 3 : out1 + ((m * H + h) * P1 + (pt - P0)) * 3;
+    o[0] = g0; o[1] = g1; o[2] = g2;
+}
+// d lin = R^T d g;  dR[a][c] += dg_a l_c;  dt += dg     (frame gradients through atomics: H P contributions per residue)
+__global__ void k_points_bwd(const float* __restrict__ lin, const float* __restrict__ rots, const float* __restrict__ dg0, const float* __restrict__ dg1,
+                             float* __restrict__ dlin, float* __restrict__ dR, float* __restrict__ dT, int M, int H, int P0, int P1) {
+    const int PT = P0 + P1;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)M * H * PT) return;
+    const int pt = (int)(idx % PT), h = (int)((idx / PT) % H);
+    const long long m = idx / ((long long)PT * H);
+    const float* g = pt < P0 ? dg0 + ((m * H + h) * P0 + pt) * 3 : dg1 + ((m * H + h) * P1 + (pt - P0)) * 3;
+    const float g0 = g[0], g1 = g[1], g2 = g[2];
+    const float* R = rots + m * 9;
+    const long long lo = m * 3 * H * PT + h * PT + pt;
+    const float l0 = lin[lo], l1 = lin[lo + H * PT], l2 = lin[lo + 2 * H * PT];
+    dlin[lo] = R[0] * g0 + R[3] * g1 + R[6] * g2;
+    dlin[lo + H * PT] = R[1] * g0 + R[4] * g1 + R[7] * g2;
+    dlin[lo + 2 * H * PT] = R[2] * g0 + R[5] * g1 + R[8] * g2;
+    float* r = dR + m * 9;
+    atomicAdd(r + 0, g0 * l0); atomicAdd(r + 1, g0 * l1); atomicAdd(r + 2, g0 * l2);
+    atomicAdd(r + 3, g1 * l0); atomicAdd(r + 4, g1 * l1); atomicAdd(r + 5, g1 * l2);
+    atomicAdd(r + 6, g2 * l0); atomicAdd(r + 7, g2 * l1); atomicAdd(r + 8, g2 * l2);
+    atomicAdd(dT + m * 3, g0); atomicAdd(dT + m * 3 + 1, g1); atomicAdd(dT + m * 3 + 2, g2);
+}
+void launch_points_fwd(hipStream_t st, const float* lin, const float* rots, const float* trans, float* out0, float* out1, int M, int H, int P0, int P1) {
+    const long long n = (long long)M * H * (P0 + P1);
+    hipLaunchKernelGGL(k_points_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, lin, rots, trans, out0, out1, M, H, P0, P1);
+}
+void launch_points_bwd(hipStream_t st, const float* lin, const float* rots, const float* dg0, const float* dg1, float* dlin, float* dR, float* dT,
+                       int M, int H, int P0, int P1) {
+    const long long n = (long long)M * H * (P0 + P1);
+    hipLaunchKernelGGL(k_points_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, lin, rots, dg0, dg1, dlin, dR, dT, M, H, P0, P1);
+}
+
+// BackboneUpdate + compose (backbone_update.py:40-66, affine_utils.py:109-116, 299-334):
+//   quat = (1, b, c, d) / sqrt(1 + b^2 + c^2 + d^2);  U = rot(quat);  R' = R U;  t' = R t_u + t
+__device__ __forceinline__ void quat_rot(const float w, const float x, const float y, const float z, float* U) {
+    U[0] = w * w + x * x - y * y - z * z; U[1] = 2 * (x * y - w * z); U[2] = 2 * (x * z + w * y);
+    U[3] = 2 * (x * y + w * z); U[4] = w * w - x * x + y * y - z * z; U[5] = 2 * (y * z - w * x);
+    U[6] = 2 * (x * z - w * y); U[7] = 2 * (y * z + w * x); U[8] = w * w - x * x - y * y + z * z;
+}
+__global__ void k_frames_fwd(const float* __restrict__ bb, const float* __restrict__ R, const float* __restrict__ T, float* __restrict__ R2,
+                             float* __restrict__ T2, int M) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float* u = bb + (size_t)m * 6;
+    const float inv = 1.0f / sqrtf(1.0f + u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    float U[9];
+    quat_rot(inv, u[0] * inv, u[1] * inv, u[2] * inv, U);
+    const float* r = R + (size_t)m * 9;
+    for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < 3; ++c) R2[(size_t)m * 9 + a * 3 + c] = r[a * 3] * U[c] + r[a * 3 + 1] * U[3 + c] + r[a * 3 + 2] * U[6 + c];
+    for (int a = 0; a < 3; ++a) T2[(size_t)m * 3 + a] = r[a * 3] * u[3] + r[a * 3 + 1] * u[4] + r[a * 3 + 2] * u[5] + T[(size_t)m * 3 + a];
+}
+// given dR', dt' (gradients wrt the composed frame): d bb [M][6], and dR += ..., dt += ... of the input frame
+__global__ void k_frames_bwd(const float* __restrict__ bb, const float* __restrict__ R, const float* __restrict__ dR2, const float* __restrict__ dT2,
+                             float* __restrict__ dbb, float* __restrict__ dR, float* __restrict__ dT, int M) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float* u = bb + (size_t)m * 6;
+    const float n2 = 1.0f + u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+    const float inv = 1.0f / sqrtf(n2);
+    const float w = inv, x = u[0] * inv, y = u[1] * inv, z = u[2] * inv;
+    float U[9];
+    quat_rot(w, x, y, z, U);
+    const float* r = R + (size_t)m * 9;
+    const float* g = dR2 + (size_t)m * 9;
+    const float* gt = dT2 + (size_t)m * 3;
+    float dU[9];            // dU = R^T dR'
+    for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < 3; ++c) dU[a * 3 + c] = r[a] * g[c] + r[3 + a] * g[3 + c] + r[6 + a] * g[6 + c];
+    for (int a = 0; a < 3; ++a) {
+        for (int c = 0; c < 3; ++c)      // dR += dR' U^T + dt' (x) t_u
+            dR[(size_t)m * 9 + a * 3 + c] += g[a * 3] * U[c * 3] + g[a * 3 + 1] * U[c * 3 + 1] + g[a * 3 + 2] * U[c * 3 + 2] + gt[a] * u[3 + c];
+        dT[(size_t)m * 3 + a] += gt[a];
+    }
+    float* o = dbb + (size_t)m * 6;
+    for (int a = 0; a < 3; ++a) o[3 + a] = r[a] * gt[0] + r[3 + a] * gt[1] + r[6 + a] * gt[2];       // d t_u = R^T dt'
+    // d (w, x, y, z) of the homogeneous quadratic form
+    const float dw = 2 * (w * dU[0] - z * dU[1] + y * dU[2] + z * dU[3] + w * dU[4] - x * dU[5] - y * dU[6] + x * dU[7] + w * dU[8]);
+    const float dx = 2 * (x * dU[0] + y * dU[1] + z * dU[2] + y * dU[3] - x * dU[4] - w * dU[5] + z * dU[6] + w * dU[7] - x * dU[8]);
+    const float dy = 2 * (-y * dU[0] + x * dU[1] + w * dU[2] + x * dU[3] + y * dU[4] + z * dU[5] - w * dU[6] + z * dU[7] - y * dU[8]);
+    const float dz = 2 * (-z * dU[0] - w * dU[1] + x * dU[2] + w * dU[3] - z * dU[4] + y * dU[5] + x * dU[6] + y * dU[7] + z * dU[8]);
+    // quat = (1, b, c, d) inv:  d b = inv dx - b inv^3 (dw + b dx + c dy + d dz)
+    const float dot = dw + u[0] * dx + u[1] * dy + u[2] * dz;
+    const float i3 = inv * inv * inv;
+    o[0] = inv * dx - u[0] * i3 * dot;
+    o[1] = inv * dy - u[1] * i3 * dot;
+    o[2] = inv * dz - u[2] * i3 * dot;
+}
+void launch_frames_fwd(hipStream_t st, const float* bb, const float* R, const float* T, float* R2, float* T2, int M) {
+    hipLaunchKernelGGL(k_frames_fwd, dim3((M + 255) / 256), dim3(256), 0, st, bb, R, T, R2, T2, M);
+}
+void launch_frames_bwd(hipStream_t st, const float* bb, const float* R, const float* dR2, const float* dT2, float* dbb, float* dR, float* dT, int M) {
+    hipLaunchKernelGGL(k_frames_bwd, dim3((M + 255) / 256), dim3(256), 0, st, bb, R, dR2, dT2, dbb, dR, dT, M);
+}

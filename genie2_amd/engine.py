@@ -147,6 +147,31 @@ class GenieEngine:
             res['grad'] = g
         return res
 
+    def train_forward_backward(self, weights, trans, rots, timesteps, z_target, condition_loss_weight=1.0, quat_codes=None, grads=None,
+                               train_mode=True, seed=0, tri_dropout=0.25, ipa_dropout=0.1, transition_dropout=0.1, fast_math=False):
+        """Forward + backward pass of Genie.training_step through the Denoiser (genie.py:88-105) for the bound batch.
+        `weights`: flat fp32 device tensor in state_dict order (pack.flatten_state_dict(...).to(device)); returns
+        dict(weighted_loss, unweighted_loss, condition_losses, infill_losses, z, grads) with `grads` a flat tensor of the same layout
+        (overwritten when passed in) -- what the optimizer (adam_step) and the DDP all-reduce act on."""
+        B, N = self.B, self.N
+        w = self._dev(weights, torch.float32)
+        assert w.dim() == 1 and w.numel() == self.lib.genie_weight_count(C.byref(capi.GenieDims(**self.dims)))
+        g = torch.empty_like(w) if grads is None else grads
+        assert g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and g.numel() == w.numel()
+        tr, ro = self._dev(trans, torch.float32), self._dev(rots, torch.float32)
+        ts, zt = self._dev(timesteps, torch.int32), self._dev(z_target, torch.float32)
+        codes = self._dev(quat_codes, torch.int8) if quat_codes is not None else None
+        opts = capi.GenieTrainOpts(float(tri_dropout), float(ipa_dropout), float(transition_dropout), int(seed) & 0xFFFFFFFF,
+                                   1 if train_mode else 0, int(fast_math))
+        out = torch.empty(2 + 2 * B, device=self.device)
+        zp = torch.empty(B, N, 3, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.genie_train_forward_backward(self._h, self._stream(), _ptr(w), _ptr(g), _ptr(tr), _ptr(ro), _ptr(ts), _ptr(zt), _ptr(codes),
+                                                       float(condition_loss_weight), C.byref(opts), _ptr(out), _ptr(zp))
+        capi.check(self._h, rc, 'genie_train_forward_backward')
+        return {'unweighted_loss': out[0], 'weighted_loss': out[1], 'condition_losses': out[2:2 + B], 'infill_losses': out[2 + B:],
+                'z': zp, 'grads': g}
+
     def denoise(self, trans, rots, timesteps, quat_codes=None, taps=()):
         """Denoiser.forward.  Returns {'z': ..., <tap>: ...}."""
         B, N = self.B, self.N

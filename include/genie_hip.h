@@ -201,6 +201,33 @@ int genie_training_loss(genie_handle_t h, genie_stream_t stream, const float* z_
 int genie_adam_step(genie_stream_t stream, size_t n, float* p, const float* g, float* m, float* v, double lr, double beta1,
                     double beta2, double eps, int step);
 
+/* The training step's forward and backward pass through the Denoiser (genie/diffusion/genie.py:88-105; what Lightning's
+ * automatic optimisation runs between training_step and the optimizer, train.py:54-65), for the batch bound with
+ * genie_prepare_features:
+ *   output = Denoiser(T(rots, trans), timesteps, features)            (train mode: dropout live, see opts)
+ *   loss   = the weighted loss of genie_training_loss(output['z'], z_target)
+ *   grads  = d loss / d weights
+ * `weights` and `grads` are DEVICE blobs owned by the caller in Denoiser.state_dict() order (the layout genie_load_weights takes
+ * from the host; genie_weight_count floats): the optimizer (genie_adam_step) and the DDP gradient all-reduce (torch.distributed
+ * over RCCL, train.py:57-59) act on them directly.  losses_out as genie_training_loss; z_pred_out [B,N,3] optional.
+ * Dropout (modules/dropout.py:23-76 row-shared on both triangle multiplications, rate tri_dropout; nn.Dropout on s + ipa(s) and
+ * inside StructureTransition, structure_net.py:109, structure_transition.py:66) uses counter-based masks derived from `seed`;
+ * train_mode = 0 gives the eval-mode forward (what tests/golden/train_grads_n16_b2.npz was recorded in).
+ * fast_math: how the GEMMs' f32 operands reach the bf16 matrix pipe -- 0: split in three bf16 pieces (24 significand bits, six MFMAs
+ * per product: f32-grade, what the parity tests run), 2: two pieces (16 bits, three MFMAs), 1: plain bf16 (one MFMA: the
+ * reference's bf16 autocast). */
+typedef struct {
+    float tri_dropout, ipa_dropout, transition_dropout;
+    uint32_t seed;
+    int32_t train_mode, fast_math;
+} genie_train_opts_t;
+int genie_train_forward_backward(genie_handle_t h, genie_stream_t stream, const float* weights, float* grads, const float* trans /*[B,N,3]*/,
+                                 const float* rots /*[B,N,3,3]*/, const int32_t* timesteps /*[B]*/, const float* z_target /*[B,N,3]*/,
+                                 const int8_t* quat_codes /*[B,N,N] or NULL*/, float condition_loss_weight, const genie_train_opts_t* opts,
+                                 float* losses_out /*[2 + 2B]*/, float* z_pred_out);
+/* Bytes of activations + scratch the last training call holds. */
+size_t genie_train_workspace_bytes(genie_handle_t h);
+
 /* ---- measurement ------------------------------------------------------- */
 
 /* Per-kernel-class HIP-event timing on the launch stream (bench.py roofline

@@ -1,0 +1,125 @@
+"""The training row (BASELINE config 5): forward + backward pass of Genie.training_step through the Denoiser on the
+GPU (genie_train_forward_backward), against the reference's own autograd (tests/golden/train_grads_n16_b2.npz) and against torch
+autograd over the oracle; dropout masks; Adam; the 2-rank DDP step (gloo, CPU part in test_host_logic.py).
+
+Tolerance of a gradient tensor: 5e-3 x its largest magnitude (the bound the oracle itself is held to against the reference).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import genie_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def t(x):
+    return torch.from_numpy(np.asarray(x))
+
+
+def flat(sd, dims):
+    from genie2_amd import pack
+    return pack.flatten_state_dict(sd, dims)
+
+
+def split(blob, dims):
+    from genie2_amd import pack
+    out, o = {}, 0
+    for k, shp in pack.weight_layout(dims):
+        n = int(np.prod(shp))
+        out[k] = blob[o:o + n].reshape(shp)
+        o += n
+    assert o == blob.numel()
+    return out
+
+
+def check_grads(got, ref, tol=5e-3):
+    """per tensor: max |difference| <= tol x the tensor's largest magnitude (floored at 1e-5 of the largest gradient of all: a tensor
+    whose true gradient vanishes -- linear_b.bias under the softmax's shift invariance -- holds only rounding noise)"""
+    worst = (0.0, None)
+    floor = 1e-5 * max(float(r.abs().max()) for r in ref.values())
+    for k, r in ref.items():
+        scale = max(float(r.abs().max()), floor)
+        d = float((got[k].cpu() - r).abs().max()) / scale
+        if d > worst[0]:
+            worst = (d, k)
+        assert d <= tol, (k, d, scale)
+    return worst
+
+
+def test_gradients_match_reference_autograd_golden(base_engine, base_weights):
+    """all 396 parameter gradients of the reference Denoiser (its own autograd, eval mode, recorded eigh signs): largest magnitude,
+    norm and the first 8 entries of each"""
+    g = load_golden('train_grads_n16_b2')
+    f = O.empty_features([int(x) for x in g['lengths']])
+    for k in ('residue_mask', 'chain_index', 'residue_index', 'fixed_sequence_mask', 'num_residues'):
+        f[k] = t(g[k])
+    f['atom_positions'] = t(g['atom_positions'])
+    dims = dict(O.BASE_DIMS)
+    base_engine.bind_features(f)
+    w = flat(base_weights, dims).cuda()
+    out = base_engine.train_forward_backward(w, t(g['trans_s']), t(g['rots_s']), t(g['s']).int(), t(g['z']),
+                                             float(g['condition_loss_weight']), quat_codes=t(g['quat_codes']), train_mode=False)
+    m = t(g['residue_mask']).unsqueeze(-1).float()          # (padded residues attend through an all -1e5 bias: not comparable, and masked in the loss)
+    assert float(((out['z'].cpu() - t(g['z_pred'])) * m).abs().max()) < 2e-4
+    assert abs(float(out['weighted_loss']) - float(g['loss'])) < 1e-4 * max(1.0, abs(float(g['loss'])))
+    gr = split(out['grads'].cpu(), dims)
+    keys = [str(k) for k in g['keys']]
+    assert keys == list(gr.keys())
+    for i, k in enumerate(keys):
+        scale = max(float(g['grad_abs_max'][i]), 1e-6)
+        assert abs(float(gr[k].abs().max()) - float(g['grad_abs_max'][i])) <= 5e-3 * scale, k
+        assert abs(float(gr[k].norm()) - float(g['grad_norm'][i])) <= 5e-3 * max(float(g['grad_norm'][i]), 1e-6), k
+        n = min(8, gr[k].numel())
+        assert float((gr[k].reshape(-1)[:n] - t(g['grad_probe'][i][:n])).abs().max()) <= 5e-3 * scale, k
+
+
+def _oracle_grads(sd, dims, rots, trans, ts, f, z, w, masks=None):
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    o = O.denoiser_forward(sdg, dims, rots, trans, ts, f, 'closed', None, None, **({'dropout_masks': masks} if masks else {}))
+    lo = O.training_loss(o['z'], z, O.prepare_features(f), w)
+    lo['weighted_loss'].backward()
+    return o['z'].detach(), lo, {k: v.grad for k, v in sdg.items()}
+
+
+def _case(seed, lengths, motif=True, chains=None):
+    g = torch.Generator().manual_seed(seed)
+    f = O.empty_features(lengths, chains_per_sample=chains)
+    B, N = f['residue_mask'].shape
+    if motif:
+        O.add_motif(f, 0, torch.randn(4, 3, generator=g) * 4, [1, 2, 3, 9])
+    f['atom_positions'] = f['atom_positions'] + 0.0
+    x0 = torch.randn(B, N, 3, generator=g) * 4 * f['residue_mask'].unsqueeze(-1)
+    f['atom_positions'] = torch.where(f['fixed_sequence_mask'].unsqueeze(-1), f['atom_positions'], x0)
+    z = torch.randn(B, N, 3, generator=g) * f['residue_mask'].unsqueeze(-1)
+    return f, z, g
+
+
+@pytest.mark.parametrize('rescale', [1.0, 2.0])
+def test_gradients_match_oracle_autograd_small_dims(rescale):
+    """ragged batch, motif conditioning, two chains, odd shapes: every gradient against torch autograd over the oracle"""
+    from genie2_amd.engine import GenieEngine
+    dims = O.small_dims(rescale=rescale)
+    sd = O.synthetic_state_dict(dims, seed=4)
+    f, z, g = _case(7, [21, 14], chains=[[9, 12], [14]])
+    B, N = f['residue_mask'].shape
+    sched = O.training_schedule(dims['n_timestep'])
+    s = torch.tensor([37, 5])
+    fr = O.prepare_features(f)
+    trans, rots = O.q_sample(f['atom_positions'], s, z, fr['chain_index'], fr['residue_mask'], sched)
+    zo, lo, gref = _oracle_grads(sd, dims, rots, trans, s.int(), f, z, 3.0)
+    eng = GenieEngine(dims, sd, 'cuda:0')
+    eng.bind_features(f)
+    out = eng.train_forward_backward(flat(sd, dims).cuda(), trans, rots, s.int(), z, 3.0, train_mode=False)
+    m = fr['residue_mask'].unsqueeze(-1).float()
+    assert float(((out['z'].cpu() - zo) * m).abs().max()) <= 2e-4 * max(1.0, float(zo.abs().max()))
+    assert abs(float(out['weighted_loss']) - float(lo['weighted_loss'].detach())) <= 1e-4 * float(lo['weighted_loss'].detach())
+    assert abs(float(out['unweighted_loss']) - float(lo['unweighted_loss'].detach())) <= 1e-4 * float(lo['unweighted_loss'].detach())
+    worst = check_grads(split(out['grads'].cpu(), dims), gref)
+    print('worst relative gradient difference', worst)
+    # the single-MFMA bf16 mode (the reference's autocast precision) stays within bf16's own accuracy
+    fast = eng.train_forward_backward(flat(sd, dims).cuda(), trans, rots, s.int(), z, 3.0, train_mode=False, fast_math=True)
+    assert abs(float(fast['weighted_loss']) - float(lo['weighted_loss'].detach())) <= 2e-2 * float(lo['weighted_loss'].detach())
+    check_grads(split(fast['grads'].cpu(), dims), gref, tol=0.25)
+    eng.close()
