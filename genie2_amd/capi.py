@@ -45,7 +45,7 @@ class GenieTaps(C.Structure):
 
 class GenieTrainOpts(C.Structure):
     _fields_ = [('tri_dropout', C.c_float), ('ipa_dropout', C.c_float), ('transition_dropout', C.c_float), ('seed', C.c_uint32),
-                ('train_mode', C.c_int32), ('fast_math', C.c_int32)]
+                ('train_mode', C.c_int32), ('fast_math', C.c_int32), ('struct_done_event', C.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/genie_hip.h declares

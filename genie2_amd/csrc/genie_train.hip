@@ -400,6 +400,7 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         std::swap(dRn, dRl); std::swap(dTn, dTl);
         T.off = mark;
     }
+    if (!dry && opt.struct_done_event) (void)hipEventRecord((hipEvent_t)opt.struct_done_event, st);      // structure_net.* gradients are final
     // ---- pair transform net, backwards.  dP = gradient wrt the pair representation leaving the current sub-layer.
     auto tri_bwd = [&](const TriOff& t, TriSave& sv, bool outgoing, uint32_t tag) {
         size_t mark = T.off;

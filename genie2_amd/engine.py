@@ -148,7 +148,8 @@ class GenieEngine:
         return res
 
     def train_forward_backward(self, weights, trans, rots, timesteps, z_target, condition_loss_weight=1.0, quat_codes=None, grads=None,
-                               train_mode=True, seed=0, tri_dropout=0.25, ipa_dropout=0.1, transition_dropout=0.1, fast_math=False):
+                               train_mode=True, seed=0, tri_dropout=0.25, ipa_dropout=0.1, transition_dropout=0.1, fast_math=False,
+                               struct_done_event=None):
         """Forward + backward pass of Genie.training_step through the Denoiser (genie.py:88-105) for the bound batch.
         `weights`: flat fp32 device tensor in state_dict order (pack.flatten_state_dict(...).to(device)); returns
         dict(weighted_loss, unweighted_loss, condition_losses, infill_losses, z, grads) with `grads` a flat tensor of the same layout
@@ -162,7 +163,8 @@ class GenieEngine:
         ts, zt = self._dev(timesteps, torch.int32), self._dev(z_target, torch.float32)
         codes = self._dev(quat_codes, torch.int8) if quat_codes is not None else None
         opts = capi.GenieTrainOpts(float(tri_dropout), float(ipa_dropout), float(transition_dropout), int(seed) & 0xFFFFFFFF,
-                                   1 if train_mode else 0, int(fast_math))
+                                   1 if train_mode else 0, int(fast_math),
+                                   C.c_void_p(struct_done_event.cuda_event) if struct_done_event is not None else None)
         out = torch.empty(2 + 2 * B, device=self.device)
         zp = torch.empty(B, N, 3, device=self.device)
         with torch.cuda.device(self.device):

@@ -88,6 +88,16 @@ def convert_tensor_features_to_numpy(features):
     return {k: features[k].detach().cpu().numpy().astype(_NP_DTYPES[k]) for k in _T_DTYPES}
 
 
+def prepare_tensor_features(features):
+    """feat_utils.py:342-359: cast a batched tensor feature dict (e.g. from a DataLoader) to the types the model reads."""
+    ints = ('num_chains', 'num_residues', 'num_residues_per_chain', 'aatype', 'residue_mask', 'residue_index', 'chain_index', 'fixed_group')
+    out = {k: features[k].int() for k in ints}
+    out['atom_positions'] = features['atom_positions'].float()
+    for k in ('fixed_sequence_mask', 'fixed_structure_mask', 'interface_mask'):
+        out[k] = features[k].bool()
+    return out
+
+
 def save_np_features_to_pdb(np_features, filepath):
     """feat_utils.py:136-186: C-alpha-only PDB, coordinates centred and rounded
     to 3 decimals, written with str(x).rjust(8) (so 14.61, not 14.610)."""

@@ -220,6 +220,8 @@ typedef struct {
     float tri_dropout, ipa_dropout, transition_dropout;
     uint32_t seed;
     int32_t train_mode, fast_math;
+    void* struct_done_event;   /* hipEvent_t or NULL: recorded on `stream` once the gradients of every structure_net.* tensor (the tail
+                                  of the blob) are final, so that their all-reduce can overlap the pair stack's backward pass */
 } genie_train_opts_t;
 int genie_train_forward_backward(genie_handle_t h, genie_stream_t stream, const float* weights, float* grads, const float* trans /*[B,N,3]*/,
                                  const float* rots /*[B,N,3,3]*/, const int32_t* timesteps /*[B]*/, const float* z_target /*[B,N,3]*/,

@@ -398,16 +398,18 @@ def pair_transition(sd, pfx, z, mask):
     return _lin(sd, pfx + 'linear_2', h) * mask.unsqueeze(-1)
 
 
-def pair_transform_net(sd, dims, p, features, taps=None):
-    """pair_transform_net.py:91-119,224-232 (dropouts are identity in eval)."""
+def pair_transform_net(sd, dims, p, features, taps=None, dropout_masks=None):
+    """pair_transform_net.py:91-119,224-232.  Dropouts are identity in eval; `dropout_masks` (train mode) maps
+    ('tri', layer, 0 | 1) to the row-shared keep-mask [B,1,N,C] (already scaled by 1 / (1 - rate), modules/dropout.py:23-76)."""
     rm = features['residue_mask']
     pm = (rm.unsqueeze(1) * rm.unsqueeze(2)).float()
+    dm = dropout_masks or {}
     for l in range(dims['n_pair_transform_layer']):
         pfx = f'pair_transform_net.net.{l}.'
-        p = p + triangle_multiplication(sd, pfx + 'tri_mul_out.', p, pm, True)
+        p = p + triangle_multiplication(sd, pfx + 'tri_mul_out.', p, pm, True) * dm.get(('tri', l, 0), 1.0)
         if taps is not None and l == 0:
             taps['p_after_trimul_out0'] = p
-        p = p + triangle_multiplication(sd, pfx + 'tri_mul_in.', p, pm, False)
+        p = p + triangle_multiplication(sd, pfx + 'tri_mul_in.', p, pm, False) * dm.get(('tri', l, 1), 1.0)
         if taps is not None and l == 0:
             taps['p_after_trimul_in0'] = p
         p = p + pair_transition(sd, pfx + 'pair_transition.', p, pm)
@@ -473,20 +475,27 @@ def backbone_update(sd, pfx, s):
     return quat_to_rot(quats), t_upd
 
 
-def structure_net(sd, dims, s, p, rots, trans, features, taps=None):
-    """structure_net.py:76-116,189-243 and modules/structure_transition.py:34-70."""
+def structure_net(sd, dims, s, p, rots, trans, features, taps=None, dropout_masks=None):
+    """structure_net.py:76-116,189-243 and modules/structure_transition.py:34-70.  `dropout_masks` (train mode):
+    ('ipa', i) on s + ipa(s) (structure_net.py:109) and ('transition', i) before the transition's LayerNorm
+    (structure_transition.py:66), i = running layer index, each [B,N,c_s] scaled by 1 / (1 - rate)."""
     mask = features['residue_mask'].float()
+    dm = dropout_masks or {}
     states = [s]                                         # structure_net.py:236-243: input + s after every layer
+    li = 0
     for _ in range(dims['n_structure_block']):
         for l in range(dims['n_structure_layer']):
             pfx = f'structure_net.net.{l}.'
             s = s + invariant_point_attention(sd, dims, pfx + 'ipa.', s, p, rots, trans, mask,
                                               taps if l == 0 else None)
+            s = s * dm.get(('ipa', li), 1.0)
             s = _ln(sd, pfx + 'ipa_layer_norm', s)
             t0 = s
             h = F.relu(_lin(sd, pfx + 'transition.layers.0.linear_1', s))
             h = F.relu(_lin(sd, pfx + 'transition.layers.0.linear_2', h))
             s = _lin(sd, pfx + 'transition.layers.0.linear_3', h) + t0
+            s = s * dm.get(('transition', li), 1.0)
+            li += 1
             s = _ln(sd, pfx + 'transition.layer_norm', s)
             if taps is not None and l == 0:
                 taps['s_after_layer0'] = s
@@ -500,7 +509,7 @@ def structure_net(sd, dims, s, p, rots, trans, features, taps=None):
 
 
 def denoiser_forward(sd, dims, rots, trans, timesteps, features, quat_mode='eigh',
-                     sign_codes=None, taps=None):
+                     sign_codes=None, taps=None, dropout_masks=None):
     """model/model.py:125-192.  Returns dict(z, s, p, s_final, rots, trans)."""
     f = prepare_features(features)
     trans0 = trans
@@ -511,8 +520,8 @@ def denoiser_forward(sd, dims, rots, trans, timesteps, features, quat_mode='eigh
     if taps is not None:
         taps['p_init'] = p
     if dims['n_pair_transform_layer'] > 0:
-        p = pair_transform_net(sd, dims, p, f, taps)
-    s_fin, r_out, t_out = structure_net(sd, dims, s, p, rots, trans, f, taps)
+        p = pair_transform_net(sd, dims, p, f, taps, dropout_masks)
+    s_fin, r_out, t_out = structure_net(sd, dims, s, p, rots, trans, f, taps, dropout_masks)
     t_out = t_out * (1. / dims['rescale'])
     return dict(z=trans0 - t_out, s=s, p=p, s_final=s_fin, rots=r_out, trans=t_out)
 
@@ -559,6 +568,32 @@ def training_loss(z_pred, z, features, condition_loss_weight):
     weighted = (w * cond + infill) / (w * torch.sum(condition_mask, dim=-1) + torch.sum(infill_mask, dim=-1))
     return dict(unweighted_loss=torch.mean(unweighted), weighted_loss=torch.mean(weighted), condition_losses=cond,
                 infill_losses=infill)
+
+
+def train_dropout_masks(dims, B, N, seed, tri_dropout=0.25, ipa_dropout=0.1, transition_dropout=0.1):
+    """The keep-masks the HIP training path derives from `seed` (csrc/train.h drop_scale: a counter-based hash of (seed, site, element
+    index)), rebuilt here so that the oracle can run the SAME train-mode forward: site tags 4 l + {0, 1} for the two triangle
+    multiplications of pair layer l (row-shared: index (b N + j) C + c), 1000 + 2 i + {0, 1} for structure layer i."""
+    import numpy as np
+
+    def scale(tag, n, rate):
+        idx = np.arange(n, dtype=np.uint64)
+        with np.errstate(over='ignore'):
+            x = ((idx & np.uint64(0xFFFFFFFF)).astype(np.uint32) * np.uint32(0x9E3779B1)) ^ ((idx >> np.uint64(32)).astype(np.uint32) * np.uint32(0x85EBCA77)) \
+                ^ (np.uint32(seed & 0xFFFFFFFF) * np.uint32(0xC2B2AE3D)) ^ (np.uint32(tag) * np.uint32(0x27D4EB2F))
+            x ^= x >> np.uint32(16); x *= np.uint32(0x85EBCA6B); x ^= x >> np.uint32(13); x *= np.uint32(0xC2B2AE35); x ^= x >> np.uint32(16)
+        u = (x >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+        return torch.from_numpy(np.where(u < np.float32(rate), np.float32(0), np.float32(1.0) / (np.float32(1.0) - np.float32(rate))).astype(np.float32))
+
+    cp, cs = dims['c_p'], dims['c_s']
+    m = {}
+    for l in range(dims['n_pair_transform_layer']):
+        for k in (0, 1):
+            m[('tri', l, k)] = scale(4 * l + k, B * N * cp, tri_dropout).reshape(B, 1, N, cp)
+    for i in range(dims['n_structure_layer'] * dims['n_structure_block']):
+        m[('ipa', i)] = scale(1000 + 2 * i, B * N * cs, ipa_dropout).reshape(B, N, cs)
+        m[('transition', i)] = scale(1001 + 2 * i, B * N * cs, transition_dropout).reshape(B, N, cs)
+    return m
 
 
 def prepare_features(features):

@@ -516,6 +516,33 @@ def gen_train_grads(sd):
          grad_probe=np.stack([probe[k].numpy() if probe[k].numel() == 8 else np.pad(probe[k].numpy(), (0, 8 - probe[k].numel())) for k in keys]))
 
 
+def gen_dataset():
+    """genie/data/dataset.py: the reference's own GenieDataset on one of the structure files it ships (results/test001/pdbs/100_0.pdb,
+    copied as a data fixture): __getitem__ with motif_prob = 1 under three (numpy, random) seeds, and the unconditional item."""
+    import random
+    import shutil
+    from genie.data.dataset import GenieDataset
+    src = os.path.join(REF, 'results', 'test001', 'pdbs', '100_0.pdb')
+    shutil.copy(src, os.path.join(OUT, 'dataset_100_0.pdb'))
+    with tempfile.TemporaryDirectory() as d:
+        shutil.copy(src, os.path.join(d, 'x100.pdb'))
+        random.seed(0)
+        ds = GenieDataset({'datadir': d, 'names': ['x100']}, 20, 128, 1, 1.0, 0.05, 0.5, 1, 4)
+        arrs = {}
+        for seed in (1, 2, 3):
+            np.random.seed(seed)
+            random.seed(seed)
+            it = ds[0]
+            for k, v in it.items():
+                arrs[f's{seed}_{k}'] = np.asarray(v)
+        ds.motif_prob = 0.0
+        np.random.seed(9)
+        it = ds[0]
+        for k, v in it.items():
+            arrs[f'u_{k}'] = np.asarray(v)
+    save('dataset_items', **arrs)
+
+
 def main():
     torch.manual_seed(0)
     print('weights (synthetic recipe, seed 0)')
@@ -534,6 +561,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'motif':
         print('motif'); gen_motif(sd)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'dataset':
+        print('dataset'); gen_dataset()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'train':
         print('train'); gen_train(); gen_train_grads(sd)
         return
@@ -545,6 +575,7 @@ def main():
     print('trajectory'); gen_trajectory(sd)
     print('motif'); gen_motif(sd)
     print('train'); gen_train(); gen_train_grads(sd)
+    print('dataset'); gen_dataset()
 
 
 if __name__ == '__main__':
