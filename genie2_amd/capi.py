@@ -67,6 +67,7 @@ SYMBOLS = {
                                   C.c_double, C.c_int]),
     'genie_train_forward_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_float, C.POINTER(GenieTrainOpts), C.c_void_p, C.c_void_p]),
+    'genie_denoise_vjp': (C.c_int, [C.c_void_p] * 10),
     'genie_train_workspace_bytes': (C.c_size_t, [C.c_void_p]),
     'genie_p_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p]),

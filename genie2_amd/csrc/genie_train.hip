@@ -118,6 +118,7 @@ struct Run {
     }
     // dW[O][K] += dY[R][O]^T X[R][K];  db[O] += column sums of dY
     void lin_bwd_w(const float* dY, long long R, int O, const float* X, long long ldx, int K, size_t w, long long b_off) {
+        if (!G) return;                     // input-gradient only (genie_denoise_vjp)
         GemmP p{dY, X, G + w, nullptr, O, K, (int)R, 1, O, ldx, 1, K, 1, 1, 1, 0, 0, 0, 0, 0, 0, splits(R), 1.0f, 2};
         gemm(p);
         if (b_off >= 0 && !dry) launch_colsum(st, dY, nullptr, R, O, G + b_off, nullptr);
@@ -129,16 +130,19 @@ struct Run {
     void ln_bwd(const float* dy, const float* xhat, const float* rstd, size_t g, size_t b, float* dx, long long R, int C, bool accumulate) {
         if (dry) return;
         launch_ln_bwd(st, dy, xhat, rstd, W + g, dx, R, C, accumulate ? 1 : 0);
-        launch_colsum(st, dy, xhat, R, C, G + b, G + g);
+        if (G) launch_colsum(st, dy, xhat, R, C, G + b, G + g);
     }
     template <class F> void ew(long long n, F f) { if (!dry) launch_ew(st, n, f); }
 };
 }  // namespace
 
 // losses_out [2 + 2B] as genie_training_loss; z_pred_out [B,N,3] optional
+// dz_in != nullptr: vector-Jacobian mode -- no loss; the cotangent of z is dz_in and dtrans_out receives d <dz_in, z> / d trans with
+// the frames held fixed (Gd may be nullptr: no weight gradients)
 static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, float* Gd, const float* trans0, const float* rots0,
                      const int32_t* ts_dev, const float* z_target, const int8_t* codes, float cond_w, const genie_train_opts_t& opt,
-                     float* losses_out, float* z_pred_out, size_t* kept_bytes, size_t* tmp_bytes) {
+                     float* losses_out, float* z_pred_out, size_t* kept_bytes, size_t* tmp_bytes, const float* dz_in = nullptr,
+                     float* dtrans_out = nullptr) {
     const genie_dims_t& d = h->d;
     const Offs O = make_offsets(d);
     Run r;
@@ -316,12 +320,14 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
     float* zp = K.f((size_t)M * 3); float* dzp = K.f((size_t)M * 3);
     { const float inv = 1.0f / d.rescale; const float* Tf = Tc; r.ew((long long)M * 3, [=] __device__(long long i) { zp[i] = trans0[i] - Tf[i] * inv; }); }
     if (!dry) {
-        launch_training_loss(h, st, zp, z_target, cond_w, losses_out, dzp);
+        if (dz_in) (void)hipMemcpyAsync(dzp, dz_in, (size_t)M * 3 * 4, hipMemcpyDeviceToDevice, st);
+        else launch_training_loss(h, st, zp, z_target, cond_w, losses_out, dzp);
         if (z_pred_out) (void)hipMemcpyAsync(z_pred_out, zp, (size_t)M * 3 * 4, hipMemcpyDeviceToDevice, st);
     }
 
     // =========================================================================================== backward
-    if (!dry) (void)hipMemsetAsync(Gd, 0, O.total * sizeof(float), st);
+    if (!dry && Gd) (void)hipMemsetAsync(Gd, 0, O.total * sizeof(float), st);
+    float* gsink = K.f(64);                      // where the IPA kernels' small atomics go when no weight gradients are wanted
     float* ds = K.f((size_t)M * cs);             // gradient wrt the single representation leaving a structure layer
     float* dRn = K.f((size_t)M * 9); float* dTn = K.f((size_t)M * 3);      // ... wrt the frames leaving it
     float* dRl = K.f((size_t)M * 9); float* dTl = K.f((size_t)M * 3);      // ... wrt the frames entering it
@@ -379,13 +385,13 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         a.B = B; a.N = N; a.H = H; a.C = C; a.Pq = Pq; a.Pv = Pv; a.cp = cp;
         a.q = v.q; a.kv = v.kv; a.qp = v.qp; a.kp = v.kp; a.vp = v.vp; a.p = z; a.rots = v.R; a.trans = v.T; a.rmask = rm;
         a.head_w = Wd + o.head; a.wb = Wd + o.b_w; a.att = v.att; a.cat = v.cat; a.dcat = dcat;
-        a.dlg = dlg; a.dq = dq; a.dqp = dqp; a.doptg = doptg; a.dP = dP; a.dhead = Gd + o.head; a.dbb = Gd + o.b_b; a.dR = dRl; a.dT = dTl;
+        a.dlg = dlg; a.dq = dq; a.dqp = dqp; a.doptg = doptg; a.dP = dP; a.dhead = Gd ? Gd + o.head : gsink; a.dbb = Gd ? Gd + o.b_b : gsink + 32; a.dR = dRl; a.dT = dTl;
         a.dkv = dkv; a.dkp = dkp; a.dvp = dvp;
         if (!dry) launch_ipa_bwd(st, a);
         {   // linear_b weight: dWb[h][c] += c_b sum_{b,i,j} dlogit[b,h,i,j] p[b,i,j,c]
-            GemmP g{dlg, z, Gd + o.b_w, nullptr, H, cp, N * N, (long long)N * N, 1, cp, 1, cp, 1, B, 1, (long long)H * N * N, 0, (long long)N * N * cp, 0, 0, 0,
+            GemmP g{dlg, z, Gd ? Gd + o.b_w : nullptr, nullptr, H, cp, N * N, (long long)N * N, 1, cp, 1, cp, 1, B, 1, (long long)H * N * N, 0, (long long)N * N * cp, 0, 0, 0,
                     Run::splits((long long)N * N), sqrtf(1.0f / 3.0f), 2};
-            r.gemm(g);
+            if (Gd) r.gemm(g);
         }
         float* dqplin = T.f((size_t)M * 3 * H * Pq); float* dkvplin = T.f((size_t)M * 3 * H * (Pq + Pv));
         if (!dry) {
@@ -502,6 +508,16 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         });
         float* dpi = T.f((size_t)M * cp); float* dpj = T.f((size_t)M * cp);
         if (!dry) launch_pair_sum_bwd(st, dP, dpi, dpj, B, N, cp);
+        if (dtrans_out) {   // d / d trans: direct term of z = trans - t_out / rescale, the initial frames' translations, the template distance bins
+            float* dFt = T.f((size_t)P * kt); float* dtr = T.f((size_t)M * 3);
+            r.lin_bwd_x(dP, P, cp, O.wt, kt, dFt, kt, false);
+            if (!dry) {
+                (void)hipMemsetAsync(dtr, 0, (size_t)M * 3 * 4, st);
+                launch_pair_features_bwd(st, dFt, kt, tr, rm, dtr, B, N, nbin, d.template_dist_min, d.template_dist_step);
+            }
+            const float sc = d.rescale; const float* dT0 = dTn;
+            r.ew((long long)M * 3, [=] __device__(long long i) { dtrans_out[i] = dzp[i] + sc * (dT0[i] + dtr[i]); });
+        }
         r.lin_bwd_w(dP, P, cp, Fm, nf, kt, O.wt, -1);
         r.lin_bwd_w(dP, P, cp, Fm + kt, nf, km, O.wm, -1);
         r.lin_bwd_w(dP, P, cp, Fm + kt + km, nf, kr, O.wrel, -1);
@@ -516,6 +532,7 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
     return GENIE_OK;
 }
 
+static int train_alloc(genie_ctx* h, hipStream_t st, size_t kb, size_t tb);
 int genie_train_forward_backward(genie_handle_t h, genie_stream_t stream, const float* weights, float* grads, const float* trans, const float* rots,
                                  const int32_t* timesteps, const float* z_target, const int8_t* quat_codes, float condition_loss_weight,
                                  const genie_train_opts_t* opts, float* losses_out, float* z_pred_out) {
@@ -527,6 +544,16 @@ int genie_train_forward_backward(genie_handle_t h, genie_stream_t stream, const 
     hipStream_t st = (hipStream_t)stream;
     size_t kb = 0, tb = 0;
     train_run(h, st, true, weights, grads, trans, rots, timesteps, z_target, quat_codes, condition_loss_weight, *opts, losses_out, z_pred_out, &kb, &tb);
+    if (int rc0 = train_alloc(h, st, kb, tb)) return rc0;
+    const int rc = train_run(h, st, false, weights, grads, trans, rots, timesteps, z_target, quat_codes, condition_loss_weight, *opts, losses_out,
+                             z_pred_out, nullptr, nullptr);
+    if (rc) return rc;
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { TR_ERR("genie_train_forward_backward: %s", hipGetErrorString(e)); return GENIE_E_HIP; }
+    return GENIE_OK;
+}
+
+static int train_alloc(genie_ctx* h, hipStream_t st, size_t kb, size_t tb) {
     if (!h->train) h->train = new genie_train_ws();
     if (kb > h->train->kept_bytes) {
         if (h->train->kept) { (void)hipStreamSynchronize(st); (void)hipFree(h->train->kept); h->train->kept = nullptr; h->train->kept_bytes = 0; }
@@ -538,11 +565,23 @@ int genie_train_forward_backward(genie_handle_t h, genie_stream_t stream, const 
         if (hipMalloc(&h->train->tmp, tb) != hipSuccess) { TR_ERR("training scratch: hipMalloc(%zu MB) failed", tb >> 20); return GENIE_E_NOMEM; }
         h->train->tmp_bytes = tb;
     }
-    const int rc = train_run(h, st, false, weights, grads, trans, rots, timesteps, z_target, quat_codes, condition_loss_weight, *opts, losses_out,
-                             z_pred_out, nullptr, nullptr);
-    if (rc) return rc;
+    return GENIE_OK;
+}
+
+int genie_denoise_vjp(genie_handle_t h, genie_stream_t stream, const float* weights, const float* trans, const float* rots, const int32_t* timesteps,
+                      const int8_t* quat_codes, const float* dz, float* z_out, float* dtrans_out) {
+    if (!h) return GENIE_E_ARG;
+    if (!h->have_tables || !h->have_feats) { TR_ERR("genie_denoise_vjp: call genie_set_tables and genie_prepare_features first"); return GENIE_E_STATE; }
+    if (!weights || !trans || !rots || !timesteps || !dz || !dtrans_out) { TR_ERR("genie_denoise_vjp: null argument"); return GENIE_E_ARG; }
+    if (hipSetDevice(h->device) != hipSuccess) return GENIE_E_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    genie_train_opts_t opt{};
+    size_t kb = 0, tb = 0;
+    train_run(h, st, true, weights, nullptr, trans, rots, timesteps, nullptr, quat_codes, 1.f, opt, nullptr, z_out, &kb, &tb, dz, dtrans_out);
+    if (int rc = train_alloc(h, st, kb, tb)) return rc;
+    train_run(h, st, false, weights, nullptr, trans, rots, timesteps, nullptr, quat_codes, 1.f, opt, nullptr, z_out, nullptr, nullptr, dz, dtrans_out);
     const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { TR_ERR("genie_train_forward_backward: %s", hipGetErrorString(e)); return GENIE_E_HIP; }
+    if (e != hipSuccess) { TR_ERR("genie_denoise_vjp: %s", hipGetErrorString(e)); return GENIE_E_HIP; }
     return GENIE_OK;
 }
 

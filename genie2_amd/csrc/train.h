@@ -22,6 +22,8 @@ void launch_transpose(hipStream_t st, const float* in, float* out, int B, int R,
 void launch_pair_features(hipStream_t st, const float* trans, const float* rots, const int8_t* codes, const float* rmask, const uint8_t* fstm,
                           const uint8_t* fsm, const float* mpos, const int32_t* ridx, const int32_t* cidx, float* F, int B, int N, int nbin,
                           float dmin, float dstep, int relk);
+void launch_pair_features_bwd(hipStream_t st, const float* dF, int ldf, const float* trans, const float* rmask, float* dtr, int B, int N, int nbin,
+                              float dmin, float dstep);
 void launch_pair_sum_bwd(hipStream_t st, const float* dp, float* dpi, float* dpj, int B, int N, int C);
 
 struct IpaArgs {

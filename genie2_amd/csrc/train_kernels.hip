@@ -281,6 +281,43 @@ void launch_pair_features(hipStream_t st, const float* trans, const float* rots,
     hipLaunchKernelGGL(k_pair_features, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, trans, rots, codes, rmask, fstm, fsm, mpos, ridx, cidx,
                        F, B, N, nbin, dmin, dstep, relk);
 }
+// gradient of the template distance bins wrt the (scaled) translations: F_k = pm softmax_k(-4 |d - v_k|), d = sqrt(1e-10 + |x_i - x_j|^2)
+// (pair_feature_net.py:223-269, geo_utils.py:4-19).  dF: [P][ldf], the first nbin columns.  The quaternion features depend on the
+// frames only, which the guidance samplers detach (unconditional_smc.py:466, 570-576).
+__global__ __launch_bounds__(256) void k_pair_features_bwd(const float* __restrict__ dF, int ldf, const float* __restrict__ trans,
+                                                           const float* __restrict__ rmask, float* __restrict__ dtr, int B, int N, int nbin,
+                                                           float dmin, float dstep) {
+    const long long pidx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (pidx >= (long long)B * N * N) return;
+    const int j = (int)(pidx % N), i = (int)((pidx / N) % N), b = (int)(pidx / ((long long)N * N));
+    const float pm = rmask[b * N + i] * rmask[b * N + j];
+    if (pm == 0.f || i == j) return;
+    const float* xi = trans + (size_t)(b * N + i) * 3;
+    const float* xj = trans + (size_t)(b * N + j) * 3;
+    const float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
+    const float d = sqrtf(1e-10f + dx * dx + dy * dy + dz * dz);
+    float mx = -3.0e38f;
+    for (int k = 0; k < nbin; ++k) mx = fmaxf(mx, -4.0f * fabsf(d - (dmin + (float)k * dstep)));
+    float s = 0.f, sg = 0.f, sfg = 0.f, sf = 0.f;
+    const float* g = dF + pidx * ldf;
+    for (int k = 0; k < nbin; ++k) {
+        const float v = dmin + (float)k * dstep;
+        const float e = expf(-4.0f * fabsf(d - v) - mx);
+        const float dl = d > v ? -4.0f : (d < v ? 4.0f : 0.f);      // d logit_k / d d
+        s += e; sg += e * dl; sfg += e * g[k] * dl; sf += e * g[k];
+    }
+    // y_k = e_k / s;  dL/dd = pm sum_k g_k y_k (dl_k - sum_m y_m dl_m)
+    const float dd = pm * (sfg / s - (sf / s) * (sg / s));
+    const float c = dd / d;
+    atomicAdd(dtr + (size_t)(b * N + i) * 3, c * dx); atomicAdd(dtr + (size_t)(b * N + i) * 3 + 1, c * dy); atomicAdd(dtr + (size_t)(b * N + i) * 3 + 2, c * dz);
+    atomicAdd(dtr + (size_t)(b * N + j) * 3, -c * dx); atomicAdd(dtr + (size_t)(b * N + j) * 3 + 1, -c * dy); atomicAdd(dtr + (size_t)(b * N + j) * 3 + 2, -c * dz);
+}
+void launch_pair_features_bwd(hipStream_t st, const float* dF, int ldf, const float* trans, const float* rmask, float* dtr, int B, int N, int nbin,
+                              float dmin, float dstep) {
+    const long long P = (long long)B * N * N;
+    hipLaunchKernelGGL(k_pair_features_bwd, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, dF, ldf, trans, rmask, dtr, B, N, nbin, dmin, dstep);
+}
+
 // p[b,i,j,:] = (p[b,i,j,:] + pi[b,i,:] + pj[b,j,:]) * mask   and its transpose: dpi[b,i,:] = sum_j dp, dpj[b,j,:] = sum_i dp
 __global__ __launch_bounds__(128) void k_pair_sum_bwd(const float* __restrict__ dp, float* __restrict__ dpi, float* __restrict__ dpj, int N, int C) {
     const int bi = blockIdx.x;                  // (b, i): row sum over j -> dpi[b, i]; and column role: (b, j = i) sum over rows

@@ -174,6 +174,20 @@ class GenieEngine:
         return {'unweighted_loss': out[0], 'weighted_loss': out[1], 'condition_losses': out[2:2 + B], 'infill_losses': out[2 + B:],
                 'z': zp, 'grads': g}
 
+    def denoise_vjp(self, weights, trans, rots, timesteps, dz, quat_codes=None):
+        """(z, d <dz, z> / d trans) with the frames held fixed: torch.autograd.grad through the denoiser as the twisted-diffusion
+        samplers use it (unconditional_smc.py:465-482).  `weights`: flat fp32 device tensor in state_dict order."""
+        w = self._dev(weights, torch.float32)
+        tr, ro = self._dev(trans, torch.float32), self._dev(rots, torch.float32)
+        ts, g = self._dev(timesteps, torch.int32), self._dev(dz, torch.float32)
+        codes = self._dev(quat_codes, torch.int8) if quat_codes is not None else None
+        z = torch.empty(self.B, self.N, 3, device=self.device)
+        dt = torch.empty(self.B, self.N, 3, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.genie_denoise_vjp(self._h, self._stream(), _ptr(w), _ptr(tr), _ptr(ro), _ptr(ts), _ptr(codes), _ptr(g), _ptr(z), _ptr(dt))
+        capi.check(self._h, rc, 'genie_denoise_vjp')
+        return z, dt
+
     def denoise(self, trans, rots, timesteps, quat_codes=None, taps=()):
         """Denoiser.forward.  Returns {'z': ..., <tap>: ...}."""
         B, N = self.B, self.N

@@ -227,6 +227,15 @@ int genie_train_forward_backward(genie_handle_t h, genie_stream_t stream, const 
                                  const float* rots /*[B,N,3,3]*/, const int32_t* timesteps /*[B]*/, const float* z_target /*[B,N,3]*/,
                                  const int8_t* quat_codes /*[B,N,N] or NULL*/, float condition_loss_weight, const genie_train_opts_t* opts,
                                  float* losses_out /*[2 + 2B]*/, float* z_pred_out);
+/* Vector-Jacobian product of the denoiser wrt its input translations, frames held fixed: what the fork's twisted-diffusion / SMC
+ * samplers take with torch.autograd.grad(log_prob, ts.trans) after ts = T(rots.detach(), trans.detach())
+ * (genie/sampler/unconditional_smc.py:465-482, 570-576):
+ *   z_out      [B,N,3] = Denoiser(T(rots, trans), timesteps, features)['z']   (eval mode; may be NULL)
+ *   dtrans_out [B,N,3] = sum over z entries of dz * d z / d trans
+ * through the direct term, the frame translations entering the structure net and every IPA layer, and the template distance
+ * bins of the pair feature net.  `weights`: device blob as for genie_train_forward_backward.  No weight gradients are formed. */
+int genie_denoise_vjp(genie_handle_t h, genie_stream_t stream, const float* weights, const float* trans, const float* rots,
+                      const int32_t* timesteps, const int8_t* quat_codes, const float* dz, float* z_out, float* dtrans_out);
 /* Bytes of activations + scratch the last training call holds. */
 size_t genie_train_workspace_bytes(genie_handle_t h);
 

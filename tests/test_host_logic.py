@@ -404,3 +404,28 @@ def test_ddp_training_step_two_ranks_equal_single_process(tmp_path):
     d = (a['w'] - w1['w']).abs()
     assert float(d.max()) <= 2e-4 and float(d.mean()) <= 1e-7
     assert abs(a['loss'] - b['loss']) >= 0.0 and float((a['w'] - torch.load(out + '.1.0')['w']).abs().max()) < 1e-3
+
+
+def test_smc_helpers_follow_the_quoted_reference_lines():
+    """genie2_amd.smc: systematic resampling against a literal restatement of unconditional_smc.py:258-283 (the while loops), the
+    weight normalisation / ESS helpers (:25-43) on known values."""
+    from genie.sampler.unconditional_smc import systematic_resampling, compute_ess_from_log_w, normalize_log_weights
+    g = torch.Generator().manual_seed(0)
+    for n in (4, 7, 16):
+        w = torch.rand(n, generator=g) ** 3 + 1e-3
+        particles = torch.arange(n * 3, dtype=torch.float32).reshape(n, 3)
+        for u in (0.0, 0.31 / n, 0.999 / n):
+            wn = w / w.sum()
+            cs = torch.cat([torch.tensor([0.0]), torch.cumsum(wn, 0)])
+            pts = [u + i / n for i in range(n)]
+            idx, j = [], 0
+            for i in range(n):
+                while pts[i] > float(cs[j + 1]) and j < n - 1:
+                    j += 1
+                idx.append(j)
+            got, neww, gi = systematic_resampling(particles, w, u)
+            assert gi.tolist() == idx and torch.equal(got, particles[torch.tensor(idx)]) and float(neww.abs().max()) == 0.0
+    lw = torch.log(torch.tensor([0.5, 0.25, 0.25]))
+    assert abs(float(compute_ess_from_log_w(lw)) - 1.0 / (0.25 + 0.0625 * 2)) < 1e-5
+    assert torch.allclose(torch.exp(normalize_log_weights(lw + 100.0, 0)), torch.tensor([0.5, 0.25, 0.25]), atol=1e-6)
+    assert abs(float(compute_ess_from_log_w(torch.zeros(8))) - 8.0) < 1e-5
