@@ -33,6 +33,9 @@
 #define FZ_SB_FLOATS 1408
 #define FZ_LDS_BYTES (2 * HX_STAGE_BYTES + 6144 + 8 * HX_ZT_BYTES)
 #define FZ_OOR 0x7FFFFFF0
+#ifndef FZ_XPRE
+#define FZ_XPRE 0          // 1: chain B fetches half of the next tile's x between the MFMAs of its last transition stages (32 registers held through the projections: 92 spills, 0.877 ms); 0: all of x at the tile's start (55 spills, 0.848 ms)
+#endif
 #ifndef FZ_SAFE
 #define FZ_SAFE 0
 #endif
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
     {
         int zs, nv, cm;
         tile_geom(tile, zs, nv, cm);
-        if (HAS_T) {
+        if (HAS_T && FZ_XPRE) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) FZ_XLOAD(c, cm);
         }
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
         // the rest of the tile's x (chunks 4..7: their lines were touched into L2 by the previous tile, fz_touch_next)
         FZ_STAMP();
 #pragma unroll
-        for (int c = HAS_T ? 4 : 0; c < 8; ++c) FZ_XLOAD(c, cmoff);      // (chain A: all of x here -- no phase of it has room to fetch ahead)
+        for (int c = (HAS_T && FZ_XPRE) ? 4 : 0; c < 8; ++c) FZ_XLOAD(c, cmoff);      // (chain A: all of x here -- no phase of it has room to fetch ahead)
         const float msk = (pl < nvalid) ? A.rmask[b * N + line] * A.rmask[b * N + t0i + pl] : 0.f;
         const bool more = tile + (int)gridDim.x < n_tiles;
         int n_zsoff = 0, n_nv = 1, n_cmoff = 0;
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
                         MFH3(wh, wl, zh[kc], zl[kc], d);
                         PIPE_FENCE();
                         wh = nh; wl = nl;
-                        if (XC >= 0 && more) xld1(raw, XC < 0 ? 0 : XC, kc, n_cmoff);
+                        if (FZ_XPRE && XC >= 0 && more) xld1(raw, XC < 0 ? 0 : XC, kc, n_cmoff);
                     }
                 }
                 h8 ah[2], al[2];
@@ -402,17 +405,17 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
                         bh = nh; bl = nl;
                     }
                 }
-                if (XC >= 0 && more) {
+                if (FZ_XPRE && XC >= 0 && more) {
                     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // everything older than this stage's 8 x loads: the next stage's weights
                     __builtin_amdgcn_sched_barrier(0);
                 } else
                     hx_stage_landed();
                 hx_stage_barrier();
             };
-            const int n_plain = n_hb >= 4 ? n_hb - 4 : n_hb;
+            const int n_plain = (FZ_XPRE && n_hb >= 4) ? n_hb - 4 : n_hb;
 #pragma unroll 1
             for (int hb = 0; hb < n_plain; ++hb) t_stage(hb, std::integral_constant<int, -1>{});
-            if (n_hb >= 4) {
+            if (FZ_XPRE && n_hb >= 4) {
                 t_stage(n_hb - 4, std::integral_constant<int, 0>{});
                 t_stage(n_hb - 3, std::integral_constant<int, 1>{});
                 t_stage(n_hb - 2, std::integral_constant<int, 2>{});

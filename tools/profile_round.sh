@@ -1,14 +1,18 @@
 #!/bin/bash
-# GPU box: the round's evidence in one call -- bench JSON (both arithmetics), rocprofv3 --kernel-trace --stats of the
-# same command, and the PMC passes (tools/pmc_profile.sh).  Usage: tools/profile_round.sh <tag>   (outputs under gpurun_out/<tag>/)
-TAG=${1:-round}
-OUT=gpurun_out/$TAG
+# GPU box: the rocprofv3 evidence of a round.  usage: tools/profile_round.sh <tag>   (e.g. r02)
+#   1. --kernel-trace --stats of the bench command            -> gpurun_out/prof_<tag>/stats  (per-kernel average durations)
+#   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes -> gpurun_out/prof_<tag>/traffic.json (HBM bytes per launch, FETCH doubled
+#      as MI355X_MICROARCH.md prescribes for gfx950)
+TAG=${1:-r02}
+OUT=gpurun_out/prof_$TAG
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
-timeout -k 10 400 python3 bench.py --steps 40 --warmup 5 > "$OUT/bench_hx.json" 2> "$OUT/bench_hx.err" || echo "bench hx failed"
-timeout -k 10 400 python3 bench.py --steps 20 --warmup 5 --math f32 --no-cpu-baseline > "$OUT/bench_f32.json" 2> "$OUT/bench_f32.err" || echo "bench f32 failed"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/stats.log" 2>&1 || echo "rocprof stats failed"
-find "$OUT/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
-bash tools/pmc_profile.sh "$OUT/pmc" > /dev/null 2>&1
-cp "$OUT/pmc/summary.txt" "$OUT/pmc_summary.txt" 2>/dev/null
-head -20 "$OUT/kernel_stats.csv"
+CMD="python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra-legs --profile-steps 1"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $CMD > "$OUT/stats.log" 2>&1 || exit 1
+echo "stats done"
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pass_fetch" -- $CMD > "$OUT/fetch.log" 2>&1 || exit 1
+echo "fetch done"
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pass_write" -- $CMD > "$OUT/write.log" 2>&1 || exit 1
+echo "write done"
+python3 tools/pmc_traffic.py "$OUT" > "$OUT/traffic_summary.txt" 2>&1
+cat "$OUT/traffic_summary.txt" | head -30
