@@ -82,6 +82,13 @@ __device__ __forceinline__ void fz_zt_read(float4 (&raw)[16], const unsigned cha
     }
 }
 
+// one k-chunk (q = 0..3 within the half the staging area holds) of this lane's row
+__device__ __forceinline__ void fz_zt_chunk(float4& a, float4& b, const unsigned char* zt, int pl, int h, int q) {
+    const int g = 4 * q + h;
+    a = *reinterpret_cast<const float4*>(zt + pl * 256 + ((g ^ (pl & 15)) << 4));
+    b = *reinterpret_cast<const float4*>(zt + pl * 256 + (((g + 2) ^ (pl & 15)) << 4));
+}
+
 // One channel half (64 channels = accumulators 2 hf, 2 hf + 1) of a result tile -> the wave's staging area in row order ->
 // global memory in whole 256-B pieces (the inverse of hx_zt_dma / fz_zt_read; rows >= nvalid are dropped).
 __device__ __forceinline__ void fz_store_half(rsrc_t rz, unsigned char* zt, const f32x16& v0, const f32x16& v1, int lane, int soff,
@@ -219,7 +226,7 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) FZ_XLOAD(c, cm);
         }
-        hx_zt_dma(rz, zt, lane, zs, zstride, nv, 0);
+        hx_zt_dma(rz, zt, lane, zs, zstride, nv, 1);
     }
     hx_stage_landed();
     __syncthreads();
@@ -260,8 +267,11 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
             hx_norm_split(xh, xl, raw, A.sx);                 // (raw = x; dead from here on)
             PIPE_FENCE();
             FZ_STAMP3();
-            float4 rawz[16];
-            float zmean = 0.f, zss = 0.f;
+            // z: its second channel half (prefetched by the previous tile) goes to registers, its first half is then fetched into the
+            // staging area and STAYS there until the gates are done -- chunks of it are read where they are used (32 live registers
+            // instead of 64 through the tightest stages).
+            float4 rz1[8];                                    // chunks 4..7
+            float zsh = 0.f, zs1 = 0.f, zs2 = 0.f;            // shifted sums for the LayerNorm statistics
 #pragma unroll
             for (int half = 0; half < 2; ++half) {            // stages 0, 1: update accumulators of channel blocks 2 half, 2 half + 1
                 issue(half + 1, half ^ 1);
@@ -283,31 +293,37 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
                     MFH3(f1, f1l, xh[kc], xl[kc], v[2 * half + 1]);
                     PIPE_FENCE();
                     f0 = n0; f0l = n0l; f1 = n1; f1l = n1l;
-                    if (half == 0 && kc == 0) fz_zt_read(rawz, zt, pl_t, h_t, 0);
-                    if (half == 0 && kc == 2) { hx_lds_done(); hx_zt_dma(rz, zt, lane_t, zsoff, zstride, znv, 1); }   // second channel half of z
-                    if (half == 1 && kc == 0) fz_zt_read(rawz, zt, pl_t, h_t, 1);         // (landed: stage 0 ended with vmcnt(0))
-                    // LayerNorm statistics of z between this stage's MFMAs (rawz stays as it is: it is also the residual)
-                    if (half == 1 && kc == 2) {
-                        float s = 0.f;
+                    if (half == 0 && kc == 0) {
 #pragma unroll
-                        for (int q = 0; q < 16; ++q) s += (rawz[q].x + rawz[q].y) + (rawz[q].z + rawz[q].w);
-                        s += __shfl_xor(s, 32);
-                        zmean = s * (1.0f / 128.0f);
+                        for (int q = 0; q < 4; ++q) fz_zt_chunk(rz1[2 * q], rz1[2 * q + 1], zt, pl_t, h_t, q);
                     }
-                    if (half == 1 && kc >= 3 && kc <= 6) {
+                    if (half == 0 && kc == 2) { hx_lds_done(); hx_zt_dma(rz, zt, lane_t, zsoff, zstride, znv, 0); }   // first channel half of z
+                    // LayerNorm statistics of z between this stage's MFMAs, as sums shifted by the row's first element
+                    if (half == 1 && kc == 1) {
+                        zsh = __shfl(rz1[0].x, lane & 31);         // (the same shift in both half-waves of a row)
 #pragma unroll
-                        for (int q = 4 * (kc - 3); q < 4 * (kc - 3) + 4; ++q) {
-                            const float a = rawz[q].x - zmean, bq = rawz[q].y - zmean, c = rawz[q].z - zmean, d = rawz[q].w - zmean;
-                            zss += (a * a + bq * bq) + (c * c + d * d);
+                        for (int q = 0; q < 8; ++q) {
+                            const float a = rz1[q].x - zsh, bq = rz1[q].y - zsh, c = rz1[q].z - zsh, d = rz1[q].w - zsh;
+                            zs1 += (a + bq) + (c + d); zs2 += (a * a + bq * bq) + (c * c + d * d);
                         }
+                    }
+                    if (half == 1 && kc >= 2 && kc <= 5) {          // (the first half landed: stage 0 ended with vmcnt(0))
+                        float4 ta, tb;
+                        fz_zt_chunk(ta, tb, zt, pl_t, h_t, kc - 2);
+                        const float a = ta.x - zsh, bq = ta.y - zsh, c = ta.z - zsh, d = ta.w - zsh;
+                        const float e = tb.x - zsh, f = tb.y - zsh, g = tb.z - zsh, hh = tb.w - zsh;
+                        zs1 += ((a + bq) + (c + d)) + ((e + f) + (g + hh));
+                        zs2 += ((a * a + bq * bq) + (c * c + d * d)) + ((e * e + f * f) + (g * g + hh * hh));
                     }
                 }
                 hx_stage_landed();
                 hx_stage_barrier();
                 FZ_STAMP();
             }
-            zss += __shfl_xor(zss, 32);
-            const float zsc = A.sx / sqrtf(zss * (1.0f / 128.0f) + GENIE_LN_EPS);
+            zs1 += __shfl_xor(zs1, 32); zs2 += __shfl_xor(zs2, 32);
+            const float zm_s = zs1 * (1.0f / 128.0f);                                  // mean - shift
+            const float zmean = zsh + zm_s;
+            const float zsc = A.sx / sqrtf(fmaxf(zs2 * (1.0f / 128.0f) - zm_s * zm_s, 0.f) + GENIE_LN_EPS);
             FZ_STAMP3();
 #pragma unroll
             for (int half = 0; half < 2; ++half) {            // stages 2, 3: gates of channel blocks 2 half, 2 half + 1, then z'
@@ -327,9 +343,10 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
                     const int kn = min(kc + 1, 7);
                     const h8 n0 = hx_frag(stage, kn, 0, lane), n0l = hx_frag(stage, kn, 1, lane), n1 = hx_frag(stage, 8 + kn, 0, lane),
                              n1l = hx_frag(stage, 8 + kn, 1, lane);
-                    const float xz[8] = {rawz[2 * kc].x - zmean, rawz[2 * kc].y - zmean, rawz[2 * kc].z - zmean, rawz[2 * kc].w - zmean,
-                                         rawz[2 * kc + 1].x - zmean, rawz[2 * kc + 1].y - zmean, rawz[2 * kc + 1].z - zmean,
-                                         rawz[2 * kc + 1].w - zmean};
+                    float4 ca, cb;
+                    if (kc < 4) fz_zt_chunk(ca, cb, zt, pl_t, h_t, kc);
+                    else { ca = rz1[2 * (kc - 4)]; cb = rz1[2 * (kc - 4) + 1]; }
+                    const float xz[8] = {ca.x - zmean, ca.y - zmean, ca.z - zmean, ca.w - zmean, cb.x - zmean, cb.y - zmean, cb.z - zmean, cb.w - zmean};
                     h8 sh, sl;
                     hx_split8(xz, zsc, sh, sl);
                     PIPE_FENCE();
@@ -338,12 +355,20 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
                     PIPE_FENCE();
                     f0 = n0; f0l = n0l; f1 = n1; f1l = n1l;
                 }
+                float4 res[8];                              // the residual rows of this stage's 64 channels: chunks 4 half .. 4 half + 3
+                if (half == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) fz_zt_chunk(res[2 * q], res[2 * q + 1], zt, pl_t, h_t, q);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) res[q] = rz1[q];
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float g0 = A.cz * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ga[r] * A.cgo));
                     const float g1 = A.cz * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gb[r] * A.cgo));
-                    // residual: channel block ob, register r <-> chunk 2 ob + (r >> 3), slot r & 7
-                    const float4 za = rawz[2 * (4 * half + (r >> 3)) + ((r & 7) >> 2)], zb = rawz[2 * (4 * half + 2 + (r >> 3)) + ((r & 7) >> 2)];
+                    // residual: channel block ob = 2 half + {0, 1}, register r <-> local chunk 2 {0, 1} + (r >> 3), slot r & 7
+                    const float4 za = res[2 * (r >> 3) + ((r & 7) >> 2)], zb = res[2 * (2 + (r >> 3)) + ((r & 7) >> 2)];
                     const float z0 = (r & 3) == 0 ? za.x : (r & 3) == 1 ? za.y : (r & 3) == 2 ? za.z : za.w;
                     const float z1 = (r & 3) == 0 ? zb.x : (r & 3) == 1 ? zb.y : (r & 3) == 2 ? zb.z : zb.w;
                     v[2 * half][r] = fmaf(v[2 * half][r], g0, z0);
@@ -470,7 +495,7 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
                     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                     FZ_STAMP2();      // the next stage's weights (and what was requested a stage ago) have landed
                     if (more) {                                // next tile: x chunks 0..3 behind passes 4, 5; z half 0 behind passes 6, 7
-                        if (pp == 2) hx_zt_dma(rz, zt, lane_t, n_zsoff, zstride, n_nv, 0, 0, 4);
+                        if (pp == 2) hx_zt_dma(rz, zt, lane_t, n_zsoff, zstride, n_nv, 1, 0, 4);
                     }
                     hx_stage_barrier();
                     FZ_STAMP();
@@ -489,7 +514,7 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
                     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                     FZ_STAMP2();
                     if (more) {
-                        if (pp == 2) hx_zt_dma(rz, zt, lane_t, n_zsoff, zstride, n_nv, 0, 4, 4);
+                        if (pp == 2) hx_zt_dma(rz, zt, lane_t, n_zsoff, zstride, n_nv, 1, 4, 4);
                     }
                     hx_stage_barrier();
                     FZ_STAMP();
