@@ -444,6 +444,125 @@ __global__ __launch_bounds__(256, 2) void k_trimul_contract_hx(const unsigned* _
     }
 }
 
+// The same contraction with ONE 512-thread work-group per matrix (b, channel) owning the whole NP x NP output (NP <= 256): every
+// operand byte leaves HBM exactly once (the 128^2 tiling above fetches each panel twice: 0.96 GB measured against 0.81 algorithmic).
+// Waves 4 (rows) x 2 (columns), wave tile 64 x 128 = 8 accumulator blocks (128 registers); K in chunks of 32: each thread stages
+// 4 + 4 b128 loads (whole 128-B lines of a row: 8 lanes x 16 B) in registers while the previous chunk is multiplied, de-interleaves
+// them with v_perm and writes hi / lo planes at row stride 80 B (conflict-free ds_read_b128 fragments); two barriers per 32-k chunk,
+// 48 MFMAs per wave between them.  Persistent over matrices, next matrix's first chunk requested before the epilogue's stores.
+#define CB_ROWB 80
+#define CB_PLANE (256 * CB_ROWB)
+__global__ __launch_bounds__(512, 1) void k_trimul_contract_hx_big(const unsigned* __restrict__ acm, const unsigned* __restrict__ bcm,
+                                                                   float* __restrict__ xcm, int NP, int n_mat, unsigned cm_bytes, float cx, int rev) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smb[];   // [A hi | A lo | B hi | B lo], 256 rows x 80 B each
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = UNI(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;              // rows 64 wm .., columns 128 wn ..
+    const int nk = NP / 32;                               // (NP is a multiple of 32)
+    const rsrc_t ra = hx_rsrc(acm, cm_bytes), rb = hx_rsrc(bcm, cm_bytes), rx = hx_rsrc(xcm, cm_bytes);
+    const int lr = tid >> 3, pc = tid & 7;                // row within a 64-row block, 16-B piece of the row's 128-B chunk
+    u32x4 rA[2][4], rB[2][4];       // two chunks in flight: chunk it + 2 is requested while chunk it is multiplied
+    auto mat_of = [&](int w) { return rev ? n_mat - 1 - w : w; };
+    auto gload = [&](int w, int kc, auto set_tag) {
+        constexpr int S = decltype(set_tag)::value;
+        const int mbase = mat_of(w) * NP * NP * 4 + kc * 128;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {     // rows past NP: voffset pushed out of the buffer -> zeros
+            const int row = 64 * u + lr;
+            const int vo = row < NP ? (row * NP * 4 + pc * 16) : 0x7FFFFFF0;
+            rA[S][u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, vo, mbase, 0));
+            rB[S][u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, vo, mbase, 0));
+        }
+    };
+    auto swrite = [&](auto set_tag) {
+        constexpr int S = decltype(set_tag)::value;
+        unsigned char* sa = smb + lr * CB_ROWB + pc * 8;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint2 ahi, alo, bhi, blo;
+            ahi.x = __builtin_amdgcn_perm(rA[S][u].y, rA[S][u].x, 0x05040100u); ahi.y = __builtin_amdgcn_perm(rA[S][u].w, rA[S][u].z, 0x05040100u);
+            alo.x = __builtin_amdgcn_perm(rA[S][u].y, rA[S][u].x, 0x07060302u); alo.y = __builtin_amdgcn_perm(rA[S][u].w, rA[S][u].z, 0x07060302u);
+            bhi.x = __builtin_amdgcn_perm(rB[S][u].y, rB[S][u].x, 0x05040100u); bhi.y = __builtin_amdgcn_perm(rB[S][u].w, rB[S][u].z, 0x05040100u);
+            blo.x = __builtin_amdgcn_perm(rB[S][u].y, rB[S][u].x, 0x07060302u); blo.y = __builtin_amdgcn_perm(rB[S][u].w, rB[S][u].z, 0x07060302u);
+            *reinterpret_cast<uint2*>(sa + 64 * u * CB_ROWB) = ahi;
+            *reinterpret_cast<uint2*>(sa + CB_PLANE + 64 * u * CB_ROWB) = alo;
+            *reinterpret_cast<uint2*>(sa + 2 * CB_PLANE + 64 * u * CB_ROWB) = bhi;
+            *reinterpret_cast<uint2*>(sa + 3 * CB_PLANE + 64 * u * CB_ROWB) = blo;
+        }
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = zero16();
+    int w = blockIdx.x;
+    if (w >= n_mat) return;
+    const int my = (n_mat - 1 - w) / gridDim.x + 1;
+    const int total = my * nk;
+    // position (matrix, chunk) of the loads issued last: two chunks ahead of the one being multiplied
+    int lw = w, lkc = 0, issued = 0;
+    auto advance = [&]() { if (lkc == nk - 1) { lw += gridDim.x; lkc = 0; } else ++lkc; };
+    gload(lw, lkc, std::integral_constant<int, 0>{}); advance(); ++issued;
+    if (issued < total) { gload(lw, lkc, std::integral_constant<int, 1>{}); advance(); ++issued; }
+    int kc = 0;
+    const int foff = (lane & 31) * CB_ROWB + (lane >> 5) * 16;
+    const bool wave_live = 64 * wm < NP && 128 * wn < NP;          // waves whose tile lies past NP only help loading
+    auto body = [&](int it, auto set_tag) {
+        const bool last_chunk = kc == nk - 1;
+        swrite(set_tag);
+        __syncthreads();
+        if (issued < total) { gload(lw, lkc, set_tag); advance(); ++issued; }
+        if (wave_live) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const unsigned char* sa = smb + foff + c * 32;
+                h8 ah[2], al[2], bh[4], bl[4];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    ah[m] = *reinterpret_cast<const h8*>(sa + (wm * 2 + m) * 32 * CB_ROWB);
+                    al[m] = *reinterpret_cast<const h8*>(sa + CB_PLANE + (wm * 2 + m) * 32 * CB_ROWB);
+                }
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    bh[n] = *reinterpret_cast<const h8*>(sa + 2 * CB_PLANE + (wn * 4 + n) * 32 * CB_ROWB);
+                    bl[n] = *reinterpret_cast<const h8*>(sa + 3 * CB_PLANE + (wn * 4 + n) * 32 * CB_ROWB);
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) MFH3(ah[m], al[m], bh[n], bl[n], acc[m][n]);
+            }
+        }
+        if (last_chunk) {
+            const int mi = mat_of(w);
+            const int vst = ((4 * (lane >> 5)) * NP + (lane & 31)) * 4;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int ib = (wm * 2 + m) * 32, jb = (wn * 4 + n) * 32;
+                    if (ib < NP && jb < NP) {
+                        const int sbase = ((mi * NP + ib) * NP + jb) * 4;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float v = acc[m][n][r] * cx;
+                            hx_store(rx, v, vst, sbase + ((r & 3) + 8 * (r >> 2)) * NP * 4);
+                        }
+                    }
+                    acc[m][n] = zero16();
+                }
+            w += gridDim.x;
+            kc = 0;
+        } else
+            ++kc;
+        __syncthreads();
+    };
+    for (int it = 0; it < total; it += 2) {
+        body(it, std::integral_constant<int, 0>{});
+        if (it + 1 < total) body(it + 1, std::integral_constant<int, 1>{});
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Triangle multiplication, output (modules/triangular_multiplicative_update.py:105-108 + residual):
 //   z += (W_z LN_out(x) + b_z) * sigmoid(W_g LN_in(z) + b_g).
@@ -836,7 +955,10 @@ static void trimul_contract_slice(genie_ctx* h, HxSlice& v, const TriMulW& w, bo
     const int rev = (int)(v.launches++ & 1);
     const unsigned* pa = transposed ? g.bcm : g.acm;
     const unsigned* pb = transposed ? g.acm : g.bcm;
-    if (g.NP >= 128) {
+    if (g.NP > 192 && g.NP <= 256 && !getenv("GENIE_CONTRACT_TILED")) {
+        hipLaunchKernelGGL(k_trimul_contract_hx_big, dim3(BC < ncu ? BC : ncu), dim3(512), 4 * CB_PLANE, st, pa, pb, g.xcm, g.NP, BC, g.cm_bytes,
+                           x.cx, rev);
+    } else if (g.NP >= 128) {
         const int tiles = (g.NP + 127) / 128;
         const int n_tiles = tiles * tiles * ((BC + 7) / 8) * 8;
         hipLaunchKernelGGL(k_trimul_contract_hx<2>, dim3(n_tiles < 3 * ncu ? n_tiles : 3 * ncu), dim3(256), 2 * 4 * 128 * CX_ROWB, st,
@@ -1030,6 +1152,7 @@ void pair_hx_kernels_init() {
 #define HX_ATTR(k) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, HX_LDS_BYTES)
     HX_ATTR((k_trimul_proj_hx<true, 8>)); HX_ATTR((k_trimul_proj_hx<false, 8>));
     HX_ATTR(k_trimul_out_hx<8>); HX_ATTR(k_trimul_out_hx_r<8>);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trimul_contract_hx_big), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * CB_PLANE);
 #undef HX_ATTR
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_transition_hx<8>), hipFuncAttributeMaxDynamicSharedMemorySize, HX_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_bias_hx), hipFuncAttributeMaxDynamicSharedMemorySize, IB_UNITS * 2048 + 96 * 4);
