@@ -44,14 +44,15 @@ PEAK_F16_MFMA_TFLOPS = 2500.0     # same table, "Peak BF16/FP16 MFMA", dense
 PEAK_HBM_GBS = 8000.0
 PMC_TRAFFIC = [os.path.join(ROOT, 'profiles', n) for n in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json')]   # newest first
 KERNEL_OF_CLASS = {'trimul_proj': 'k_trimul_proj', 'trimul_contract': 'k_trimul_contract', 'trimul_out': 'k_trimul_out',
-                   'pair_transition': 'k_pair_transition'}
+                   'pair_transition': 'k_pair_transition', 'pair_fused_a': 'k_pair_fused<true, false>', 'pair_fused_b': 'k_pair_fused<false, true>'}
 
 
 def algorithmic_bytes(dims, B, N):
     """HBM bytes per launch each pair-stack kernel class cannot avoid: every
     [B,N,N,128] f32 tensor it consumes or produces once (split f16 pairs are 4 bytes too)."""
     t = 4.0 * B * N * N * dims['c_p']
-    return {'trimul_proj': 3 * t, 'trimul_contract': 3 * t, 'trimul_out': 3 * t, 'pair_transition': 2 * t}
+    # fused chains (pair_fused_kernels.hip): x and z in; z, a and b out -- the transition inside chain B moves nothing
+    return {'trimul_proj': 3 * t, 'trimul_contract': 3 * t, 'trimul_out': 3 * t, 'pair_transition': 2 * t, 'pair_fused_a': 5 * t, 'pair_fused_b': 5 * t}
 
 
 def measured_traffic(cls, math):
@@ -83,12 +84,15 @@ def algorithmic_flops(dims, B, N):
     """FLOP per launch of each MFMA kernel class."""
     M = B * N * N
     c = dims['c_p']
-    return {
+    f = {
         'trimul_proj': 2.0 * M * c * 4 * dims['c_hidden_mul'],
         'trimul_contract': 2.0 * B * dims['c_hidden_mul'] * N ** 3,
         'trimul_out': 2.0 * M * c * c * 2,
         'pair_transition': 2.0 * M * c * c * dims['pair_transition_n'] * 2,
     }
+    f['pair_fused_a'] = f['trimul_out'] + f['trimul_proj']                              # TriMul-out output -> TriMul-in projections
+    f['pair_fused_b'] = f['trimul_out'] + f['pair_transition'] + f['trimul_proj']       # TriMul-in output -> transition -> next projections
+    return f
 
 
 def step_flops(dims, B, N):
@@ -280,6 +284,9 @@ def main():
                            if kk in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms')}
                        for k in flops if k in kern and k != dom}
         whole = step_flops(dims, B, N) * (K / dt) / 1e12
+        # algorithmic pair-tensor passes of the launches this step actually made (+ 8 IPA reads + 1 pair_init write)
+        nbytes_step = sum(algorithmic_bytes(dims, B, N)[k] * v['launches_per_step'] for k, v in kern.items() if k in flops) \
+            + 9 * 4.0 * B * N * N * dims['c_p']
         out = {
             'metric': 'denoise-steps/sec (N=256, T=1000, batch=8)', 'value': value, 'unit': 'batch-steps/s',
             'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': dt / K * 1e3, 'higher_is_better': True,
@@ -291,6 +298,9 @@ def main():
                        'parallelism': f'replica per GPU x{world}, no data-path collective'},
             'structure_steps_per_s': value * B,
             'whole_step_tflops': whole,
+            'whole_step_hbm': {'algorithmic_gb': nbytes_step / 1e9, 'achieved_gbs': nbytes_step / (dt / K) / 1e9,
+                               'frac_of_8tbs': nbytes_step / (dt / K) / 1e9 / PEAK_HBM_GBS,
+                               'unfused_reference_gb': 109 * 4.0 * B * N * N * dims['c_p'] / 1e9},
             'finite': finite, 'roofline': roof, 'other_pair_kernel_rooflines': other_roofs,
             'kernels': {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in kern.items()},
         }

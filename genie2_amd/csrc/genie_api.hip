@@ -429,11 +429,9 @@ int genie_load_weights(genie_handle_t h, const float* blob, size_t n_floats) {
         for (int l = 0; l < d.n_pair_transform_layer; ++l) {
             hxfix.push_back({&h->pair[l].fa.img, hx.begin()});
             emit_O(tm_save[2 * l]); emit_P(tm_save[2 * l + 1]);
-            h->pair[l].fb.img = nullptr;
-            if (l + 1 < d.n_pair_transform_layer) {
-                hxfix.push_back({&h->pair[l].fb.img, hx.begin()});
-                emit_O(tm_save[2 * l + 1]); emit_T(pt_save[l]); emit_P(tm_save[2 * l + 2]);
-            }
+            hxfix.push_back({&h->pair[l].fb.img, hx.begin()});
+            emit_O(tm_save[2 * l + 1]); emit_T(pt_save[l]);
+            if (l + 1 < d.n_pair_transform_layer) emit_P(tm_save[2 * l + 2]);      // (the last block's chain ends with its transition)
         }
     }
     const size_t H = d.n_head_ipa, C = d.c_hidden_ipa, Pq = d.n_qk_point, Pv = d.n_v_point;

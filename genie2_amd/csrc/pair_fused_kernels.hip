@@ -147,7 +147,7 @@ __device__ __forceinline__ void fz_split_tile(h8 (&zh)[8], h8 (&zl)[8], const f3
     }
 }
 
-template <bool COL, bool HAS_T>
+template <bool COL, bool HAS_T, bool HAS_P = true>
 __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
     float* sb = reinterpret_cast<float*>(smb + 2 * HX_STAGE_BYTES);
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
     const int rev = A.rev;
     const int n_hb = HAS_T ? A.n_hb : 0;
     const int PBASE = 4 + n_hb;                              // first projection stage of the image
-    const rsrc_t rw = hx_rsrc(A.wimg, (unsigned)((PBASE + 8) * HX_STAGE_BYTES));
+    const rsrc_t rw = hx_rsrc(A.wimg, (unsigned)((PBASE + (HAS_P ? 8 : 0)) * HX_STAGE_BYTES));
     const rsrc_t rx = hx_rsrc(A.xcm, A.cm_bytes), rz = hx_rsrc(A.z, A.z_bytes);
     const rsrc_t ra = hx_rsrc(A.acm, A.cm_bytes), rb = hx_rsrc(A.bcm, A.cm_bytes);
     const int lane16 = lane * 16;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
         else if (u < FZ_SB_B1) v = A.bgs[u - FZ_SB_BG];
         else if (u < FZ_SB_B2) { if (HAS_T && u - FZ_SB_B1 < n_hb * 32) v = A.b1s[u - FZ_SB_B1]; }
         else if (u < FZ_SB_BP) { if (HAS_T) v = A.b2s[u - FZ_SB_B2]; }
-        else v = A.bproj[u - FZ_SB_BP];
+        else if (HAS_P) v = A.bproj[u - FZ_SB_BP];
         sb[u] = v;
     }
     // Input prefetch, one tile ahead: the first channel half of a tile's z rows (staging area, requested behind projection passes
@@ -394,7 +394,8 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
             // first GEMM (the transition has no memory traffic of its own; a burst at a stage's end would not be overlapped)
             auto t_stage = [&](int hb, auto xc_tag) {
                 constexpr int XC = decltype(xc_tag)::value;
-                issue(4 + hb + 1, (hb + 1) & 1);               // (hb = n_hb - 1: the first projection stage)
+                if (HAS_P || hb + 1 < n_hb) issue(4 + hb + 1, (hb + 1) & 1);     // (hb = n_hb - 1: the first projection stage ...
+                else if (more) issue(0, 0);                                      //  ... or, in the chain without projections, the next tile's first stage)
                 const unsigned char* stage = smb + (hb & 1) * HX_STAGE_BYTES;
                 f32x16 d;
 #pragma unroll
@@ -461,16 +462,19 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
         fz_store_half(rz, zt, v[2], v[3], lane_t, zsoff, zstride, nvalid, 1);
         FZ_FULL_WAIT(64);
         FZ_STAMP3();
-        {
+        if constexpr (HAS_P) {
             float mean, sc;
             fz_stats(v, A.sx, mean, sc);
             fz_split_tile(zh, zl, v, mean, sc);
         }
         hx_lds_done();                                        // the staging area is free for the next tile's z
         FZ_STAMP();
+        if constexpr (!HAS_P) {                               // (last block: no projections follow; the next tile's z half is requested here)
+            if (more) hx_zt_dma(rz, zt, lane_t, n_zsoff, zstride, n_nv, 1);
+        }
 
         // ------------------------------------------------------------------ P: a = (W_ap zn + b) sigmoid(W_ag zn + b) mask, b likewise
-        {
+        if constexpr (HAS_P) {
             const float* sbias = sbt + FZ_SB_BP;
             const float cg = A.cg;
             const float ma = msk * A.cpa, mb = msk * A.cpb;
@@ -550,11 +554,14 @@ static int fz_num_cu() {
 void pair_fused_kernels_init() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_fused<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, FZ_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_fused<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FZ_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_fused<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, FZ_LDS_BYTES);
 }
 
 // chain A of block `w` (col = true):  output of w.out (x^T in xcm) -> projections of w.in
 // chain B (col = false):              output of w.in -> transition of w -> projections of next->out
-void launch_pair_fused(genie_ctx* h, hipStream_t st, const HxFusedW& f, const HxTriW& o, const HxTransW* t, const HxTriW& p, bool col) {
+// p == nullptr: the last block's chain (output of w.in -> transition), no projections
+void launch_pair_fused(genie_ctx* h, hipStream_t st, const HxFusedW& f, const HxTriW& o, const HxTransW* t, const HxTriW* pp, bool col) {
+    const HxTriW& p = pp ? *pp : o;
     const int N = h->N, NP = h->NP, ntile = (N + 31) / 32;
     FusedArgs a;
     a.z = h->p; a.xcm = h->xcm; a.rmask = h->rmaskf; a.wimg = f.img;
@@ -570,6 +577,7 @@ void launch_pair_fused(genie_ctx* h, hipStream_t st, const HxFusedW& f, const Hx
     { const char* e = getenv("GENIE_FZ_STAGGER"); a.stagger = e ? atoi(e) : 0; }
     const long long n_tiles = ((long long)a.n_wtiles + 7) / 8;
     const unsigned grid = (unsigned)(n_tiles < fz_num_cu() ? n_tiles : fz_num_cu());
-    if (col) hipLaunchKernelGGL((k_pair_fused<true, false>), dim3(grid), dim3(512), FZ_LDS_BYTES, st, a);
+    if (!pp) hipLaunchKernelGGL((k_pair_fused<false, true, false>), dim3(grid), dim3(512), FZ_LDS_BYTES, st, a);
+    else if (col) hipLaunchKernelGGL((k_pair_fused<true, false>), dim3(grid), dim3(512), FZ_LDS_BYTES, st, a);
     else hipLaunchKernelGGL((k_pair_fused<false, true>), dim3(grid), dim3(512), FZ_LDS_BYTES, st, a);
 }

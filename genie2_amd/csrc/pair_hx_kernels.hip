@@ -994,7 +994,7 @@ static void trimul_slice(genie_ctx* h, HxSlice& v, const TriMulW& w, bool outgoi
 // The whole pair transform net with the row-local chains fused (pair_fused_kernels.hip):
 //   proj(out_0) | per block: contract^T, chain A, contract, chain B (last block: output + transition)
 // 4 launches per block instead of 7; z is read and written once per chain.  GENIE_NO_PAIR_FUSE=1 keeps the separate launches.
-void launch_pair_fused(genie_ctx* h, hipStream_t st, const HxFusedW& f, const HxTriW& o, const HxTransW* t, const HxTriW& p, bool col);
+void launch_pair_fused(genie_ctx* h, hipStream_t st, const HxFusedW& f, const HxTriW& o, const HxTransW* t, const HxTriW* p, bool col);
 bool launch_pair_stack_fused(genie_ctx* h, hipStream_t st, float* tap_trimul_out0, float* tap_layer0) {
     const int L = h->d.n_pair_transform_layer;
     if (!h->hx || L < 1 || getenv("GENIE_NO_PAIR_FUSE") || (getenv("GENIE_HX_SLICE") && atoi(getenv("GENIE_HX_SLICE")) > 0)) return false;
@@ -1006,18 +1006,18 @@ bool launch_pair_stack_fused(genie_ctx* h, hipStream_t st, float* tap_trimul_out
         const PairLayerW& W = h->pair[l];
         trimul_contract_slice(h, v, W.out, true);
         h->hx_launches = v.launches;
-        { ProfScope ps(h, st, KC_PAIR_FUSED_A); launch_pair_fused(h, st, W.fa, W.out.hx, nullptr, W.in.hx, true); }
+        { ProfScope ps(h, st, KC_PAIR_FUSED_A); launch_pair_fused(h, st, W.fa, W.out.hx, nullptr, &W.in.hx, true); }
         v.launches = h->hx_launches;
         if (l == 0 && tap_trimul_out0) (void)hipMemcpyAsync(tap_trimul_out0, h->p, pbytes, hipMemcpyDeviceToDevice, st);
         trimul_contract_slice(h, v, W.in, false);
         if (l + 1 < L) {
             h->hx_launches = v.launches;
-            { ProfScope ps(h, st, KC_PAIR_FUSED_B); launch_pair_fused(h, st, W.fb, W.in.hx, &W.hx_pt, h->pair[l + 1].out.hx, false); }
+            { ProfScope ps(h, st, KC_PAIR_FUSED_B); launch_pair_fused(h, st, W.fb, W.in.hx, &W.hx_pt, &h->pair[l + 1].out.hx, false); }
             v.launches = h->hx_launches;
-        } else {
-            trimul_out_slice(h, v, W.in);
-            ProfScope ps(h, st, KC_PAIR_TRANSITION);
-            pair_transition_slice(h, v, W);
+        } else {       // last block: the same chain without projections
+            h->hx_launches = v.launches;
+            { ProfScope ps(h, st, KC_PAIR_FUSED_B); launch_pair_fused(h, st, W.fb, W.in.hx, &W.hx_pt, nullptr, false); }
+            v.launches = h->hx_launches;
         }
         if (l == 0 && tap_layer0) (void)hipMemcpyAsync(tap_layer0, h->p, pbytes, hipMemcpyDeviceToDevice, st);
     }
