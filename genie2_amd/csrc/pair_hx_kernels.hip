@@ -460,7 +460,10 @@ __global__ __launch_bounds__(512, 1) void k_trimul_contract_hx_big(const unsigne
     const int wm = wave >> 1, wn = wave & 1;              // rows 64 wm .., columns 128 wn ..
     const int nk = NP / 32;                               // (NP is a multiple of 32)
     const rsrc_t ra = hx_rsrc(acm, cm_bytes), rb = hx_rsrc(bcm, cm_bytes), rx = hx_rsrc(xcm, cm_bytes);
-    const int lr = tid >> 3, pc = tid & 7;                // row within a 64-row block, 16-B piece of the row's 128-B chunk
+    // row within a 64-row block, 16-B piece of the row's 128-B chunk.  Consecutive 8-lane groups take rows r and r + 4 (not r + 1):
+    // the two rows a 16-lane ds_write_b64 group covers are then 320 B apart = 16 banks of the 32 a store sees, so they do not collide
+    const int gq = tid >> 3, pc = tid & 7;
+    const int lr = (gq & 0x38) | ((gq & 1) << 2) | ((gq >> 1) & 3);
     u32x4 rA[2][4], rB[2][4];       // two chunks in flight: chunk it + 2 is requested while chunk it is multiplied
     auto mat_of = [&](int w) { return rev ? n_mat - 1 - w : w; };
     auto gload = [&](int w, int kc, auto set_tag) {

@@ -3,15 +3,16 @@
 OUT=${1:-gpurun_out/pmcq}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d "$OUT/pass1" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 > "$OUT/pass1.log" 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_INSTS_SALU --output-format csv -d "$OUT/pass2" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 > "$OUT/pass2.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d "$OUT/pass1" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs --profile-steps 1 > "$OUT/pass1.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_INSTS_SALU --output-format csv -d "$OUT/pass2" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs --profile-steps 1 > "$OUT/pass2.log" 2>&1
 python3 tools/pmc_summary.py "$OUT" > "$OUT/summary.txt" 2>&1
+rm -rf "$OUT/pass1" "$OUT/pass2"      # raw counter CSVs: tens of MB
 python3 - "$OUT/summary.txt" <<'PY'
 import re, sys
 txt = open(sys.argv[1]).read()
 for blk in txt.split('== ')[1:]:
     name = blk.split()[0]
-    if not any(k in name for k in ('trimul', 'transition', 'ipa_attn', 'gemm_rows', 'ipa_bias', 'pair_init')):
+    if not any(k in name for k in ('trimul', 'transition', 'ipa_attn', 'gemm_rows', 'ipa_bias', 'pair_init', 'pair_fused')):
         continue
     c = {m.group(1): float(m.group(2)) for m in re.finditer(r'^\s+(\S+)\s+([\d.]+)\s*$', blk, re.M)}
     us = float(re.search(r'avg_us=([\d.]+)', blk).group(1))

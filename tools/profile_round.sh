@@ -15,4 +15,6 @@ echo "fetch done"
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pass_write" -- $CMD > "$OUT/write.log" 2>&1 || exit 1
 echo "write done"
 python3 tools/pmc_traffic.py "$OUT" > "$OUT/traffic_summary.txt" 2>&1
+cp "$OUT"/stats/*/*_kernel_stats.csv "$OUT/rocprofv3_kernel_stats.csv" 2>/dev/null
+rm -rf "$OUT/stats" "$OUT/pass_fetch" "$OUT/pass_write"      # raw traces are tens of MB: only the summaries travel back
 cat "$OUT/traffic_summary.txt" | head -30
