@@ -2,6 +2,7 @@
 the reference CLI (genie/sample_unconditional.py:132-159):
 outdir/pdbs/{length}_{index}.pdb."""
 import argparse
+import os
 
 from tqdm import tqdm
 
@@ -17,7 +18,7 @@ class UnconditionalRunner(MultiProcessor):
                 for length in range(params['max_length'], params['min_length'] - 1, -params['length_step'])]
 
     def create_constants(self, params):
-        return {k: params[k] for k in ('rootdir', 'name', 'epoch', 'scale', 'outdir', 'num_samples', 'batch_size')}
+        return {k: params.get(k) for k in ('rootdir', 'name', 'epoch', 'scale', 'outdir', 'num_samples', 'batch_size', 'resume')}
 
     def load_model(self, constants, device):
         return load_pretrained_model(constants['rootdir'], constants['name'], constants['epoch']).eval().to(device)
@@ -28,6 +29,12 @@ class UnconditionalRunner(MultiProcessor):
             remaining = constants['num_samples']
             while remaining > 0:
                 batch = min(constants['batch_size'], remaining)
+                offset = constants['num_samples'] - remaining
+                if constants.get('resume') and all(
+                        os.path.exists(os.path.join(constants['outdir'], 'pdbs', '{}_{}.pdb'.format(task['length'], offset + i)))
+                        for i in range(batch)):
+                    remaining -= batch           # this batch was written by an earlier (interrupted) run
+                    continue
                 sampler.sample({
                     'length': task['length'], 'scale': constants['scale'], 'num_samples': batch,
                     'outdir': constants['outdir'], 'prefix': str(task['length']),
@@ -49,6 +56,7 @@ def build_parser():
     p.add_argument('--length_step', type=int, help='Length step size', default=1)
     p.add_argument('--num_devices', type=int, help='Number of GPU devices', default=1)
     p.add_argument('--sequential_order', action='store_true', help='Run in increasing order of length')
+    p.add_argument('--resume', action='store_true', help='Skip batches whose PDB files already exist (not in the reference CLI)')
     return p
 
 

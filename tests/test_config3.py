@@ -156,6 +156,16 @@ def test_unconditional_runner_end_to_end(tmp_path, base_weights):
             sampler.sample({'length': n, 'scale': 0.6, 'num_samples': batch, 'outdir': out2, 'prefix': str(n), 'offset': offset})
     for name in files:
         assert open(os.path.join(out, 'pdbs', name), 'rb').read() == open(os.path.join(out2, 'pdbs', name), 'rb').read(), name
+    # --resume (not in the reference CLI): an interrupted run is continued, finished batches are not sampled again
+    victim = os.path.join(out, 'pdbs', '66_4.pdb')
+    os.unlink(victim)
+    stamps = {n: os.path.getmtime(os.path.join(out, 'pdbs', n)) for n in files if n != '66_4.pdb'}
+    args2 = build_parser().parse_args(['--name', 'base', '--epoch', '7', '--rootdir', root, '--scale', '0.6', '--outdir', out,
+                                       '--min_length', '50', '--max_length', '82', '--length_step', '16', '--batch_size', '4',
+                                       '--num_samples', '5', '--num_devices', '1', '--resume'])
+    UnconditionalRunner().run(vars(args2), 1, False)
+    assert os.path.exists(victim)
+    assert all(os.path.getmtime(os.path.join(out, 'pdbs', n)) == t for n, t in stamps.items())
 
 
 def test_rebinding_same_shape_cpu_features_is_not_skipped(base_weights):

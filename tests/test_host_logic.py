@@ -144,7 +144,7 @@ def test_cli_flags_and_task_split():
     from genie2_amd.sample_unconditional import UnconditionalRunner, build_parser
     from genie2_amd.multiprocessor import split_tasks
     a = build_parser().parse_args(['--name', 'base', '--epoch', '40', '--scale', '0.6', '--outdir', 'o'])
-    assert (a.num_samples, a.batch_size, a.min_length, a.max_length, a.length_step, a.num_devices) == (5, 4, 50, 256, 1, 1)
+    assert (a.num_samples, a.batch_size, a.min_length, a.max_length, a.length_step, a.num_devices) == (5, 4, 50, 256, 1, 1) and a.resume is False
     tasks = UnconditionalRunner().create_tasks(dict(min_length=50, max_length=256, length_step=16))
     assert [t['length'] for t in tasks] == list(range(256, 49, -16)) and len(tasks) == 13      # 50 itself is never visited
     bins = split_tasks(tasks, 8)

@@ -315,3 +315,28 @@ def test_twisted_sampler_constant_potential_is_the_ancestral_sampler_and_guidanc
 
     assert all(np.isfinite(it['atom_positions']).all() for it in guided)
     assert motif_rmsd(guided) < motif_rmsd(ref)
+
+
+def test_two_structure_blocks_share_weights_in_both_paths():
+    """n_structure_block = 2 (structure_net.py:189-243: the layer stack is applied twice with the same weights): the sampling path's
+    z and the training path's gradients (each weight's gradient is the sum over both applications) against the oracle."""
+    from genie2_amd.engine import GenieEngine
+    dims = O.small_dims(n_structure_block=2)
+    sd = O.synthetic_state_dict(dims, seed=12)
+    f, z, g = _case(23, [18, 13])
+    B, N = f['residue_mask'].shape
+    fr = O.prepare_features(f)
+    sched = O.training_schedule(dims['n_timestep'])
+    s = torch.tensor([77, 20])
+    trans, rots = O.q_sample(f['atom_positions'], s, z, fr['chain_index'], fr['residue_mask'], sched)
+    zo, lo, gref = _oracle_grads(sd, dims, rots, trans, s.int(), f, z, 1.0)
+    eng = GenieEngine(dims, sd, 'cuda:0')
+    eng.bind_features(f)
+    m = fr['residue_mask'].unsqueeze(-1).float()
+    zs = eng.denoise(trans, rots, s.int(), None, taps=('states',))
+    assert zs['states'].shape[0] == 1 + 2 * dims['n_structure_layer']
+    assert float(((zs['z'].cpu() - zo) * m).abs().max()) <= 1e-4 * max(1.0, float(zo.abs().max()))
+    out = eng.train_forward_backward(flat(sd, dims).cuda(), trans, rots, s.int(), z, 1.0, train_mode=False)
+    assert abs(float(out['weighted_loss']) - float(lo['weighted_loss'].detach())) <= 1e-4 * float(lo['weighted_loss'].detach())
+    check_grads(split(out['grads'].cpu(), dims), gref)
+    eng.close()
