@@ -104,8 +104,22 @@ struct Run {
     int B, N, M; long long P;
 
     // ---- GEMM shapes -------------------------------------------------------------------------------------------------------
-    static int splits(long long K) { long long s = (K + 8191) / 8192; return (int)(s < 1 ? 1 : (s > 128 ? 128 : s)); }
-    void gemm(const GemmP& p) { if (!dry) launch_gemm(st, p, terms); }
+    void gemm(const GemmP& p) {
+        if (dry) return;
+        static const bool log = getenv("GENIE_TRAIN_GEMM_LOG") != nullptr;      // developer aid: one line per GEMM with its own duration
+        if (!log) { launch_gemm(st, p, terms); return; }
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, st);
+        launch_gemm(st, p, terms);
+        (void)hipEventRecord(e1, st);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        fprintf(stderr, "GEMM M %d N %d K %d batch %d nsplit %d ak %lld bk %lld cn %lld mode %d us %.1f\n", p.M, p.N, p.K, p.batch, p.nsplit, p.ak, p.bk,
+                p.cn, p.mode, ms * 1e3f);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
     // Y[R][O] = X[R][K] (ld ldx) W[O][K]^T + b
     void lin_fwd(const float* X, long long ldx, long long R, int K, size_t w, long long b_off, int O, float* Y, int mode = 0) {
         GemmP p{X, W + w, Y, b_off >= 0 ? W + b_off : nullptr, (int)R, O, K, ldx, 1, 1, K, O, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0f, mode};
@@ -119,7 +133,7 @@ struct Run {
     // dW[O][K] += dY[R][O]^T X[R][K];  db[O] += column sums of dY
     void lin_bwd_w(const float* dY, long long R, int O, const float* X, long long ldx, int K, size_t w, long long b_off) {
         if (!G) return;                     // input-gradient only (genie_denoise_vjp)
-        GemmP p{dY, X, G + w, nullptr, O, K, (int)R, 1, O, ldx, 1, K, 1, 1, 1, 0, 0, 0, 0, 0, 0, splits(R), 1.0f, 2};
+        GemmP p{dY, X, G + w, nullptr, O, K, (int)R, 1, O, ldx, 1, K, 1, 1, 1, 0, 0, 0, 0, 0, 0, gemm_splits(O, K, R, 1), 1.0f, 2};
         gemm(p);
         if (b_off >= 0 && !dry) launch_colsum(st, dY, nullptr, R, O, G + b_off, nullptr);
     }
@@ -390,7 +404,7 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         if (!dry) launch_ipa_bwd(st, a);
         {   // linear_b weight: dWb[h][c] += c_b sum_{b,i,j} dlogit[b,h,i,j] p[b,i,j,c]
             GemmP g{dlg, z, Gd ? Gd + o.b_w : nullptr, nullptr, H, cp, N * N, (long long)N * N, 1, cp, 1, cp, 1, B, 1, (long long)H * N * N, 0, (long long)N * N * cp, 0, 0, 0,
-                    Run::splits((long long)N * N), sqrtf(1.0f / 3.0f), 2};
+                    gemm_splits(H, cp, (long long)N * N, B), sqrtf(1.0f / 3.0f), 2};
             if (Gd) r.gemm(g);
         }
         float* dqplin = T.f((size_t)M * 3 * H * Pq); float* dkvplin = T.f((size_t)M * 3 * H * (Pq + Pv));

@@ -14,6 +14,7 @@ struct GemmP {
     int nsplit; float alpha; int mode;
 };
 void launch_gemm(hipStream_t st, const GemmP& p, int terms);
+int gemm_splits(long long M, long long N, long long K, long long batch);
 
 void launch_ln_fwd(hipStream_t st, const float* x, const float* g, const float* b, float* y, float* xhat, float* rstd, long long R, int C);
 void launch_ln_bwd(hipStream_t st, const float* dy, const float* xhat, const float* rstd, const float* g, float* dx, long long R, int C, int accumulate);

@@ -19,64 +19,123 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // ------------------------------------------------------------------------------------------------ GEMM
+// 64 x 64 output tile per 256-thread work-group (four waves, one 32 x 32 accumulator each), K in steps of 64.  An operand tile is
+// 64 rows x 64 k of f32 = four float4 per thread, fetched one step ahead into registers, split into its bf16 pieces on the way into
+// LDS ([piece][row][k], row stride 144 B: the fragment reads (16 B per lane, 32 rows) and the 8-byte stores are conflict-free).
+// Either dimension of an operand may be the contiguous one: KC = along k (lanes walk k; a float4 is four k of one row), otherwise
+// along the row index (a float4 is four rows of one k; a thread holds a 4 x 4 block and stores its transpose).  `vec`: the operand's
+// base, its other stride and its batch strides are multiples of four floats, so whole float4 loads are legal; weights inside the
+// caller's flat state_dict blob often are not (a 6-float bias shifts everything behind it) and are fetched dword by dword.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#define GM_LD 72
+
+template <bool KC>
+__device__ __forceinline__ void gm_load(const float* __restrict__ base, long long sr, long long sk, int rows_left, int k_left, bool vec, int tid,
+                                        float4 (&v)[4]) {
+    if (KC) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f = tid + 256 * q, kq = f & 15, rr = f >> 4;
+            const float* s = base + (long long)rr * sr + (long long)(4 * kq) * sk;
+            if (vec && rr < rows_left && 4 * kq + 3 < k_left) v[q] = *reinterpret_cast<const float4*>(s);
+            else {
+                const bool ro = rr < rows_left;
+                v[q].x = (ro && 4 * kq + 0 < k_left) ? s[0] : 0.f;
+                v[q].y = (ro && 4 * kq + 1 < k_left) ? s[sk] : 0.f;
+                v[q].z = (ro && 4 * kq + 2 < k_left) ? s[2 * sk] : 0.f;
+                v[q].w = (ro && 4 * kq + 3 < k_left) ? s[3 * sk] : 0.f;
+            }
+        }
+    } else {
+        const int kg = (tid & 7) + 8 * ((tid >> 6) & 1), mq = ((tid >> 3) & 7) + 8 * (tid >> 7);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kk = 4 * kg + i;
+            const float* s = base + (long long)kk * sk + (long long)(4 * mq) * sr;
+            if (vec && kk < k_left && 4 * mq + 3 < rows_left) v[i] = *reinterpret_cast<const float4*>(s);
+            else {
+                const bool ko = kk < k_left;
+                v[i].x = (ko && 4 * mq + 0 < rows_left) ? s[0] : 0.f;
+                v[i].y = (ko && 4 * mq + 1 < rows_left) ? s[sr] : 0.f;
+                v[i].z = (ko && 4 * mq + 2 < rows_left) ? s[2 * sr] : 0.f;
+                v[i].w = (ko && 4 * mq + 3 < rows_left) ? s[3 * sr] : 0.f;
+            }
+        }
+    }
+}
 template <int TERMS>
-__global__ __launch_bounds__(256) void k_gemm(const GemmP p) {
-    __shared__ __attribute__((aligned(16))) __bf16 As[TERMS][64][40];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[TERMS][64][40];
+__device__ __forceinline__ void gm_put(__bf16 (*S)[64][GM_LD], int row, int k, float a, float b, float c, float d) {
+    const float x[4] = {a, b, c, d};
+    bf16x4 h, m, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = (__bf16)x[j];
+        if (TERMS > 1) {
+            const float r1 = x[j] - (float)h[j];
+            m[j] = (__bf16)r1;
+            if (TERMS > 2) l[j] = (__bf16)(r1 - (float)m[j]);
+        }
+    }
+    *reinterpret_cast<bf16x4*>(&S[0][row][k]) = h;
+    if (TERMS > 1) *reinterpret_cast<bf16x4*>(&S[1][row][k]) = m;
+    if (TERMS > 2) *reinterpret_cast<bf16x4*>(&S[2][row][k]) = l;
+}
+template <int TERMS, bool KC>
+__device__ __forceinline__ void gm_store(__bf16 (*S)[64][GM_LD], int tid, const float4 (&v)[4]) {
+    if (KC) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f = tid + 256 * q;
+            gm_put<TERMS>(S, f >> 4, 4 * (f & 15), v[q].x, v[q].y, v[q].z, v[q].w);
+        }
+    } else {
+        const int kg = (tid & 7) + 8 * ((tid >> 6) & 1), mq = ((tid >> 3) & 7) + 8 * (tid >> 7);
+        gm_put<TERMS>(S, 4 * mq + 0, 4 * kg, v[0].x, v[1].x, v[2].x, v[3].x);
+        gm_put<TERMS>(S, 4 * mq + 1, 4 * kg, v[0].y, v[1].y, v[2].y, v[3].y);
+        gm_put<TERMS>(S, 4 * mq + 2, 4 * kg, v[0].z, v[1].z, v[2].z, v[3].z);
+        gm_put<TERMS>(S, 4 * mq + 3, 4 * kg, v[0].w, v[1].w, v[2].w, v[3].w);
+    }
+}
+
+template <int TERMS, bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void k_gemm(const GemmP p, const int vecA, const int vecB) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[TERMS][64][GM_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[TERMS][64][GM_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
     const int bz = blockIdx.z / p.nsplit, sp = blockIdx.z % p.nsplit;
     const int z1 = bz / p.nb2, z2 = bz % p.nb2;
-    const float* A = p.A + z1 * p.a1 + z2 * p.a2;
-    const float* B = p.B + z1 * p.b1 + z2 * p.b2;
+    const float* A = p.A + z1 * p.a1 + z2 * p.a2 + (long long)m0 * p.am;
+    const float* B = p.B + z1 * p.b1 + z2 * p.b2 + (long long)n0 * p.bn;
     float* C = p.C + z1 * p.c1 + z2 * p.c2;
-    const int ks = ((p.K + p.nsplit - 1) / p.nsplit + 31) / 32 * 32;
+    const int ks = ((p.K + p.nsplit - 1) / p.nsplit + 63) / 64 * 64;
     const int kbeg = sp * ks, kend = min(p.K, kbeg + ks);
+    if (kbeg >= kend) return;                               // uniform per work-group (mode 2 accumulates: nothing to add)
+    const int mleft = p.M - m0, nleft = p.N - n0;
     f32x16 acc = zero16();
-    for (int k0 = kbeg; k0 < kend; k0 += 32) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int e = tid + 256 * q;
-            {
-                int kk, mm;
-                if (p.ak == 1) { kk = e & 31; mm = e >> 5; } else { mm = e & 63; kk = e >> 6; }
-                const float v = (m0 + mm < p.M && k0 + kk < kend) ? A[(long long)(m0 + mm) * p.am + (long long)(k0 + kk) * p.ak] : 0.f;
-                const __bf16 hi = (__bf16)v;
-                As[0][mm][kk] = hi;
-                if (TERMS > 1) {
-                    const float r1 = v - (float)hi;
-                    const __bf16 mid = (__bf16)r1;
-                    As[1][mm][kk] = mid;
-                    if (TERMS > 2) As[2][mm][kk] = (__bf16)(r1 - (float)mid);
-                }
-            }
-            {
-                int kk, nn;
-                if (p.bk == 1) { kk = e & 31; nn = e >> 5; } else { nn = e & 63; kk = e >> 6; }
-                const float v = (n0 + nn < p.N && k0 + kk < kend) ? B[(long long)(k0 + kk) * p.bk + (long long)(n0 + nn) * p.bn] : 0.f;
-                const __bf16 hi = (__bf16)v;
-                Bs[0][nn][kk] = hi;
-                if (TERMS > 1) {
-                    const float r1 = v - (float)hi;
-                    const __bf16 mid = (__bf16)r1;
-                    Bs[1][nn][kk] = mid;
-                    if (TERMS > 2) Bs[2][nn][kk] = (__bf16)(r1 - (float)mid);
-                }
-            }
-        }
+    float4 va[4], vb[4];
+    gm_load<AKC>(A + (long long)kbeg * p.ak, p.am, p.ak, mleft, kend - kbeg, vecA != 0, tid, va);
+    gm_load<BKC>(B + (long long)kbeg * p.bk, p.bn, p.bk, nleft, kend - kbeg, vecB != 0, tid, vb);
+    for (int k0 = kbeg; k0 < kend; k0 += 64) {
+        gm_store<TERMS, AKC>(As, tid, va);
+        gm_store<TERMS, BKC>(Bs, tid, vb);
         __syncthreads();
+        if (k0 + 64 < kend) {
+            gm_load<AKC>(A + (long long)(k0 + 64) * p.ak, p.am, p.ak, mleft, kend - k0 - 64, vecA != 0, tid, va);
+            gm_load<BKC>(B + (long long)(k0 + 64) * p.bk, p.bn, p.bk, nleft, kend - k0 - 64, vecB != 0, tid, vb);
+        }
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < 4; ++c) {
             const int ko = c * 16 + 8 * (lane >> 5);
             const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&As[0][wm * 32 + (lane & 31)][ko]);
             const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bs[0][wn * 32 + (lane & 31)][ko]);
             if (TERMS > 1) {     // small terms first
-                const bf16x8 am = *reinterpret_cast<const bf16x8*>(&As[1][wm * 32 + (lane & 31)][ko]);
-                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(&Bs[1][wn * 32 + (lane & 31)][ko]);
+                const bf16x8 am = *reinterpret_cast<const bf16x8*>(&As[TERMS > 1 ? 1 : 0][wm * 32 + (lane & 31)][ko]);
+                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(&Bs[TERMS > 1 ? 1 : 0][wn * 32 + (lane & 31)][ko]);
                 if (TERMS > 2) {
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&As[2][wm * 32 + (lane & 31)][ko]);
-                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bs[2][wn * 32 + (lane & 31)][ko]);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&As[TERMS > 2 ? 2 : 0][wm * 32 + (lane & 31)][ko]);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bs[TERMS > 2 ? 2 : 0][wn * 32 + (lane & 31)][ko]);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
@@ -104,13 +163,35 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmP p) {
     }
 }
 
+template <int TERMS>
+static void launch_gemm_t(hipStream_t st, const GemmP& p, dim3 grid, bool akc, bool bkc, int vecA, int vecB) {
+    if (akc && bkc) hipLaunchKernelGGL((k_gemm<TERMS, true, true>), grid, dim3(256), 0, st, p, vecA, vecB);
+    else if (akc) hipLaunchKernelGGL((k_gemm<TERMS, true, false>), grid, dim3(256), 0, st, p, vecA, vecB);
+    else if (bkc) hipLaunchKernelGGL((k_gemm<TERMS, false, true>), grid, dim3(256), 0, st, p, vecA, vecB);
+    else hipLaunchKernelGGL((k_gemm<TERMS, false, false>), grid, dim3(256), 0, st, p, vecA, vecB);
+}
 // terms: bf16 pieces per operand -- 1: plain bf16 (one MFMA per product), 2: 16 significand bits (three MFMAs), 3: 24 bits (six)
 void launch_gemm(hipStream_t st, const GemmP& p, int terms) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.batch <= 0) return;
     const dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, p.batch * p.nsplit);
-    if (terms <= 1) hipLaunchKernelGGL(k_gemm<1>, grid, dim3(256), 0, st, p);
-    else if (terms == 2) hipLaunchKernelGGL(k_gemm<2>, grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(k_gemm<3>, grid, dim3(256), 0, st, p);
+    // lanes walk k unless the row index is the operand's only unit stride
+    const bool akc = p.ak == 1 || p.am != 1, bkc = p.bk == 1 || p.bn != 1;
+    auto mult4 = [](long long v) { return (v & 3) == 0; };
+    const int vecA = ((akc ? p.ak == 1 : p.am == 1) && mult4(akc ? p.am : p.ak) && mult4(p.a1) && mult4(p.a2) && ((uintptr_t)p.A & 15) == 0) ? 1 : 0;
+    const int vecB = ((bkc ? p.bk == 1 : p.bn == 1) && mult4(bkc ? p.bn : p.bk) && mult4(p.b1) && mult4(p.b2) && ((uintptr_t)p.B & 15) == 0) ? 1 : 0;
+    if (terms <= 1) launch_gemm_t<1>(st, p, grid, akc, bkc, vecA, vecB);
+    else if (terms == 2) launch_gemm_t<2>(st, p, grid, akc, bkc, vecA, vecB);
+    else launch_gemm_t<3>(st, p, grid, akc, bkc, vecA, vecB);
+}
+// split-K factor for a reduction of length K into `tiles` output tiles (x batch): enough work-groups to fill the chip, at least 128 of
+// K each.  Only for mode 2 (atomic accumulation).
+int gemm_splits(long long M, long long N, long long K, long long batch) {
+    const long long tiles = ((M + 63) / 64) * ((N + 63) / 64) * batch;
+    long long s = (768 + tiles - 1) / tiles;
+    const long long smax = (K + 127) / 128;
+    if (s > smax) s = smax;
+    if (s > 512) s = 512;
+    return (int)(s < 1 ? 1 : s);
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm (eps 1e-5, affine)
@@ -174,17 +255,39 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, co
     }
 }
 // column sums over rows: out_b[c] += sum_r a[r,c];  out_g[c] += sum_r a[r,c] w[r,c]   (LayerNorm gamma / beta and Linear bias gradients)
+// 256 threads = (256 / C) row groups x C columns (C < 256), or one row group looping over the columns; rows of a block are summed
+// in registers, row groups through LDS, blocks with one atomic per column.
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ a, const float* __restrict__ w, long long R, int C, int rows_per_block,
                                                 float* __restrict__ out_b, float* __restrict__ out_g) {
+    __shared__ float red[2][256];
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float sb = 0.f, sg = 0.f;
-        for (long long r = r0; r < r1; ++r) {
+    const int tid = threadIdx.x;
+    if (C >= 256) {
+        for (int c = tid; c < C; c += 256) {
+            float sb = 0.f, sg = 0.f;
+            for (long long r = r0; r < r1; ++r) {
+                const float v = a[r * C + c];
+                sb += v;
+                if (w) sg += v * w[r * C + c];
+            }
+            if (out_b) atomicAdd(out_b + c, sb);
+            if (out_g) atomicAdd(out_g + c, sg);
+        }
+        return;
+    }
+    const int nrg = 256 / C, c = tid % C, rg = tid / C;
+    float sb = 0.f, sg = 0.f;
+    if (rg < nrg)
+        for (long long r = r0 + rg; r < r1; r += nrg) {
             const float v = a[r * C + c];
             sb += v;
             if (w) sg += v * w[r * C + c];
         }
+    red[0][tid] = sb; red[1][tid] = sg;
+    __syncthreads();
+    if (rg == 0) {
+        for (int g = 1; g < nrg; ++g) { sb += red[0][g * C + c]; sg += red[1][g * C + c]; }
         if (out_b) atomicAdd(out_b + c, sb);
         if (out_g) atomicAdd(out_g + c, sg);
     }
@@ -196,7 +299,8 @@ void launch_ln_bwd(hipStream_t st, const float* dy, const float* xhat, const flo
     hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, dy, xhat, rstd, g, dx, R, C, accumulate);
 }
 void launch_colsum(hipStream_t st, const float* a, const float* w, long long R, int C, float* out_b, float* out_g) {
-    const int rpb = 256;
+    int rpb = (int)((R + 1023) / 1024);
+    if (rpb < 16) rpb = 16;
     hipLaunchKernelGGL(k_colsum, dim3((unsigned)((R + rpb - 1) / rpb)), dim3(256), 0, st, a, w, R, C, rpb, out_b, out_g);
 }
 
