@@ -13,6 +13,7 @@
 // Reference lines are cited per kernel; the derivatives are checked tensor by tensor against the reference's own autograd
 // (tests/golden/train_grads_n16_b2.npz) and against torch autograd over the oracle.
 #include <stdint.h>
+#include <stdlib.h>
 #include "common.h"
 #include "train.h"
 
@@ -27,18 +28,45 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // base, its other stride and its batch strides are multiples of four floats, so whole float4 loads are legal; weights inside the
 // caller's flat state_dict blob often are not (a 6-float bias shifts everything behind it) and are fetched dword by dword.
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-#define GM_LD 72
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#ifndef GM_BK
+#define GM_BK 32         // K per step: 32 -> 30 KiB of LDS with three pieces, four work-groups per CU (their phases interleave)
+#endif
+#define GM_LD (GM_BK + 8)   // row stride 80 B (144 B for 64): fragment reads and packed stores are conflict-free
+#define GM_NV (GM_BK / 16)  // float4 per thread and operand tile
+#define GM_WPS (GM_BK == 32 ? 4 : 2)
+#ifndef GM_EXP
+#define GM_EXP 0      // developer knock-outs (tools/probe/gemm_variants.sh): 1 no MFMA, 2 no global loads, 4 no result store, 8 hi piece only
+#endif
 
+// `full` (rows_left >= 64 and k_left >= GM_BK) is uniform over the work-group: full tiles -- nearly all of them -- load without a
+// per-lane test, so that a step's float4 go out back to back; edge tiles test every element.
+// KC: float4 f = tid + 256 q is k quad f % (GM_BK / 4) of row f / (GM_BK / 4).  Otherwise thread (kg, mq) holds rows 4 mq .. + 3 at
+// k = GM_NV kg .. + GM_NV - 1 (one float4 per k).
 template <bool KC>
 __device__ __forceinline__ void gm_load(const float* __restrict__ base, long long sr, long long sk, int rows_left, int k_left, bool vec, int tid,
-                                        float4 (&v)[4]) {
+                                        float4 (&v)[GM_NV]) {
+    const bool full = rows_left >= 64 && k_left >= GM_BK;
+    constexpr int QK = GM_BK / 4;                           // k quads per row
     if (KC) {
+        if (full && vec) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int f = tid + 256 * q, kq = f & 15, rr = f >> 4;
-            const float* s = base + (long long)rr * sr + (long long)(4 * kq) * sk;
-            if (vec && rr < rows_left && 4 * kq + 3 < k_left) v[q] = *reinterpret_cast<const float4*>(s);
-            else {
+            for (int q = 0; q < GM_NV; ++q) {
+                const int f = tid + 256 * q;
+                v[q] = *reinterpret_cast<const float4*>(base + (long long)(f / QK) * sr + 4 * (f % QK));
+            }
+        } else if (full) {
+#pragma unroll
+            for (int q = 0; q < GM_NV; ++q) {
+                const int f = tid + 256 * q;
+                const float* s = base + (long long)(f / QK) * sr + (long long)(4 * (f % QK)) * sk;
+                v[q].x = s[0]; v[q].y = s[sk]; v[q].z = s[2 * sk]; v[q].w = s[3 * sk];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < GM_NV; ++q) {
+                const int f = tid + 256 * q, kq = f % QK, rr = f / QK;
+                const float* s = base + (long long)rr * sr + (long long)(4 * kq) * sk;
                 const bool ro = rr < rows_left;
                 v[q].x = (ro && 4 * kq + 0 < k_left) ? s[0] : 0.f;
                 v[q].y = (ro && 4 * kq + 1 < k_left) ? s[sk] : 0.f;
@@ -48,12 +76,20 @@ __device__ __forceinline__ void gm_load(const float* __restrict__ base, long lon
         }
     } else {
         const int kg = (tid & 7) + 8 * ((tid >> 6) & 1), mq = ((tid >> 3) & 7) + 8 * (tid >> 7);
+        if (full && vec) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int kk = 4 * kg + i;
-            const float* s = base + (long long)kk * sk + (long long)(4 * mq) * sr;
-            if (vec && kk < k_left && 4 * mq + 3 < rows_left) v[i] = *reinterpret_cast<const float4*>(s);
-            else {
+            for (int i = 0; i < GM_NV; ++i) v[i] = *reinterpret_cast<const float4*>(base + (long long)(GM_NV * kg + i) * sk + 4 * mq);
+        } else if (full) {
+#pragma unroll
+            for (int i = 0; i < GM_NV; ++i) {
+                const float* s = base + (long long)(GM_NV * kg + i) * sk + (long long)(4 * mq) * sr;
+                v[i].x = s[0]; v[i].y = s[sr]; v[i].z = s[2 * sr]; v[i].w = s[3 * sr];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < GM_NV; ++i) {
+                const int kk = GM_NV * kg + i;
+                const float* s = base + (long long)kk * sk + (long long)(4 * mq) * sr;
                 const bool ko = kk < k_left;
                 v[i].x = (ko && 4 * mq + 0 < rows_left) ? s[0] : 0.f;
                 v[i].y = (ko && 4 * mq + 1 < rows_left) ? s[sr] : 0.f;
@@ -63,70 +99,196 @@ __device__ __forceinline__ void gm_load(const float* __restrict__ base, long lon
         }
     }
 }
-template <int TERMS>
-__device__ __forceinline__ void gm_put(__bf16 (*S)[64][GM_LD], int row, int k, float a, float b, float c, float d) {
-    const float x[4] = {a, b, c, d};
-    bf16x4 h, m, l;
+// NP consecutive k of one row: split into the bf16 pieces, one packed LDS store per piece
+template <int TERMS, int NP>
+__device__ __forceinline__ void gm_put(__bf16 (*S)[64][GM_LD], int row, int k, const float (&x)[NP]) {
+    typedef __bf16 vec_t __attribute__((ext_vector_type(NP)));
+    vec_t h, m, l;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NP; ++j) {
         h[j] = (__bf16)x[j];
+        if (GM_EXP & 8) { m[j] = h[j]; l[j] = h[j]; continue; }
         if (TERMS > 1) {
             const float r1 = x[j] - (float)h[j];
             m[j] = (__bf16)r1;
             if (TERMS > 2) l[j] = (__bf16)(r1 - (float)m[j]);
         }
     }
-    *reinterpret_cast<bf16x4*>(&S[0][row][k]) = h;
-    if (TERMS > 1) *reinterpret_cast<bf16x4*>(&S[1][row][k]) = m;
-    if (TERMS > 2) *reinterpret_cast<bf16x4*>(&S[2][row][k]) = l;
+    *reinterpret_cast<vec_t*>(&S[0][row][k]) = h;
+    if (TERMS > 1) *reinterpret_cast<vec_t*>(&S[1][row][k]) = m;
+    if (TERMS > 2) *reinterpret_cast<vec_t*>(&S[2][row][k]) = l;
 }
 template <int TERMS, bool KC>
-__device__ __forceinline__ void gm_store(__bf16 (*S)[64][GM_LD], int tid, const float4 (&v)[4]) {
+__device__ __forceinline__ void gm_store(__bf16 (*S)[64][GM_LD], int tid, const float4 (&v)[GM_NV]) {
     if (KC) {
+        constexpr int QK = GM_BK / 4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < GM_NV; ++q) {
             const int f = tid + 256 * q;
-            gm_put<TERMS>(S, f >> 4, 4 * (f & 15), v[q].x, v[q].y, v[q].z, v[q].w);
+            const float x[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+            gm_put<TERMS, 4>(S, f / QK, 4 * (f % QK), x);
         }
     } else {
         const int kg = (tid & 7) + 8 * ((tid >> 6) & 1), mq = ((tid >> 3) & 7) + 8 * (tid >> 7);
-        gm_put<TERMS>(S, 4 * mq + 0, 4 * kg, v[0].x, v[1].x, v[2].x, v[3].x);
-        gm_put<TERMS>(S, 4 * mq + 1, 4 * kg, v[0].y, v[1].y, v[2].y, v[3].y);
-        gm_put<TERMS>(S, 4 * mq + 2, 4 * kg, v[0].z, v[1].z, v[2].z, v[3].z);
-        gm_put<TERMS>(S, 4 * mq + 3, 4 * kg, v[0].w, v[1].w, v[2].w, v[3].w);
+        float x0[GM_NV], x1[GM_NV], x2[GM_NV], x3[GM_NV];
+#pragma unroll
+        for (int i = 0; i < GM_NV; ++i) { x0[i] = v[i].x; x1[i] = v[i].y; x2[i] = v[i].z; x3[i] = v[i].w; }
+        gm_put<TERMS, GM_NV>(S, 4 * mq + 0, GM_NV * kg, x0);
+        gm_put<TERMS, GM_NV>(S, 4 * mq + 1, GM_NV * kg, x1);
+        gm_put<TERMS, GM_NV>(S, 4 * mq + 2, GM_NV * kg, x2);
+        gm_put<TERMS, GM_NV>(S, 4 * mq + 3, GM_NV * kg, x3);
     }
 }
 
+// A persistent grid: work-group w walks the tiles wv, wv + G, ... (wv: w renumbered so that consecutive tiles -- the n-tiles that
+// share rows of A, the tiles of one K split -- run on one XCD and meet in its L2) and its loop runs over (tile, K step) pairs: the
+// first operand tiles of the next output tile are in flight while the current one finishes its MFMAs and stores its result.
+struct GmTile { const float* A; const float* B; float* C; int m0, n0, kbeg, kend, sp; };
+__device__ __forceinline__ GmTile gm_tile(const GemmP& p, int t, int MT, int NT, int ks) {
+    const int per_b = MT * NT * p.nsplit;
+    const int bz = t / per_b, r1 = t - bz * per_b;
+    const int sp = r1 / (MT * NT), r2 = r1 - sp * (MT * NT);
+    const int mt = r2 / NT, nt = r2 - mt * NT;
+    const int z1 = bz / p.nb2, z2 = bz - z1 * p.nb2;
+    GmTile q;
+    q.m0 = mt * 64; q.n0 = nt * 64; q.sp = sp;
+    q.kbeg = sp * ks; q.kend = min(p.K, q.kbeg + ks);
+    q.A = p.A + z1 * p.a1 + z2 * p.a2 + (long long)q.m0 * p.am;
+    q.B = p.B + z1 * p.b1 + z2 * p.b2 + (long long)q.n0 * p.bn;
+    q.C = p.C + z1 * p.c1 + z2 * p.c2;
+    return q;
+}
+
+// The loop is rotated so that each of load / LDS store / MFMA block / result store appears once in the code (hipcc otherwise keeps
+// every call site's lane offsets live across the loop: 316 registers and one work-group per CU): an iteration requests step i,
+// multiplies step i - 1 out of LDS (and stores the tile that step finished), then moves step i from registers into LDS.
 template <int TERMS, bool AKC, bool BKC>
-__global__ __launch_bounds__(256) void k_gemm(const GemmP p, const int vecA, const int vecB) {
+__global__ __launch_bounds__(256, GM_WPS) void k_gemm(const GemmP p, const int vecA, const int vecB, const int total) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[TERMS][64][GM_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[TERMS][64][GM_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int G = gridDim.x;                                // a multiple of 8
+    const int MT = (p.M + 63) / 64, NT = (p.N + 63) / 64;
+    const int ks = ((p.K + p.nsplit - 1) / p.nsplit + GM_BK - 1) / GM_BK * GM_BK;
+    // a K split past the end of K has nothing to add (mode 2)
+    auto skip_empty = [&](int u) { while (u < total) { const int sp = (u % (MT * NT * p.nsplit)) / (MT * NT); if (sp * ks < p.K) break; u += G; } return u; };
+    int t = skip_empty((blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3));
+    bool valid = t < total;                                 // the step being requested exists
+    GmTile rq = gm_tile(p, valid ? t : 0, MT, NT, ks);      // ... and belongs to this tile, at k = rk
+    int rk = rq.kbeg;
+    bool have = false, last = false;                        // LDS holds a step; it is its tile's last
+    GmTile cur = rq;                                        // the tile of the step in LDS
+    f32x16 acc = zero16();
+    float4 va[GM_NV], vb[GM_NV];
+    if (GM_EXP & 2) for (int i = 0; i < GM_NV; ++i) va[i] = vb[i] = make_float4(1.f, 2.f, 3.f, (float)tid);
+    while (true) {
+        if (valid && !(GM_EXP & 2)) {
+            gm_load<AKC>(rq.A + (long long)rk * p.ak, p.am, p.ak, p.M - rq.m0, rq.kend - rk, vecA != 0, tid, va);
+            gm_load<BKC>(rq.B + (long long)rk * p.bk, p.bn, p.bk, p.N - rq.n0, rq.kend - rk, vecB != 0, tid, vb);
+        }
+        if (have) {
+#pragma unroll
+            for (int c = 0; c < ((GM_EXP & 1) ? 0 : GM_BK / 16); ++c) {
+                const int ko = c * 16 + 8 * (lane >> 5);
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&As[0][wm * 32 + (lane & 31)][ko]);
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bs[0][wn * 32 + (lane & 31)][ko]);
+                if (TERMS > 1) {     // small terms first
+                    const bf16x8 am = *reinterpret_cast<const bf16x8*>(&As[TERMS > 1 ? 1 : 0][wm * 32 + (lane & 31)][ko]);
+                    const bf16x8 bm = *reinterpret_cast<const bf16x8*>(&Bs[TERMS > 1 ? 1 : 0][wn * 32 + (lane & 31)][ko]);
+                    if (TERMS > 2) {
+                        const bf16x8 al = *reinterpret_cast<const bf16x8*>(&As[TERMS > 2 ? 2 : 0][wm * 32 + (lane & 31)][ko]);
+                        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bs[TERMS > 2 ? 2 : 0][wn * 32 + (lane & 31)][ko]);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+            }
+            if (last) {
+                const int col = cur.n0 + wn * 32 + (lane & 31);
+                if (col < p.N && !((GM_EXP & 4) && acc[0] != 12345.f)) {
+                    const float bv = (p.bias && cur.sp == 0) ? p.bias[col] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = cur.m0 + wm * 32 + acc_row(r, lane);
+                        if (row >= p.M) continue;
+                        float* d = cur.C + (long long)row * p.cm + (long long)col * p.cn;
+                        const float v = acc[r] * p.alpha + bv;
+                        if (p.mode == 0) *d = v;
+                        else if (p.mode == 1) *d += v;
+                        else atomicAdd(d, v);
+                    }
+                }
+                acc = zero16();
+            }
+            __syncthreads();                                // every wave has read the step out of LDS
+        }
+        if (!valid) break;
+        gm_store<TERMS, AKC>(As, tid, va);
+        gm_store<TERMS, BKC>(Bs, tid, vb);
+        __syncthreads();
+        have = true; cur = rq; last = rk + GM_BK >= rq.kend;
+        if (!last) rk += GM_BK;
+        else {
+            t = skip_empty(t + G);
+            valid = t < total;
+            if (valid) { rq = gm_tile(p, t, MT, NT, ks); rk = rq.kbeg; }
+        }
+    }
+}
+
+// ---- the fast path: M and N multiples of 64, every K range a multiple of GM_BK, one unit stride per operand, offsets below 2^31.
+// Nothing is tested per element, a tile is a grid index, a lane's offsets into its operand tiles are computed once (32 bit) and the
+// uniform tile pointers advance by one step; float4 loads are declared 4-byte aligned (weights inside the flat blob).
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+template <int TERMS, bool AKC, bool BKC>
+__global__ __launch_bounds__(256, GM_WPS) void k_gemm_fast(const GemmP p) {
     __shared__ __attribute__((aligned(16))) __bf16 As[TERMS][64][GM_LD];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[TERMS][64][GM_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
-    const int bz = blockIdx.z / p.nsplit, sp = blockIdx.z % p.nsplit;
-    const int z1 = bz / p.nb2, z2 = bz % p.nb2;
-    const float* A = p.A + z1 * p.a1 + z2 * p.a2 + (long long)m0 * p.am;
-    const float* B = p.B + z1 * p.b1 + z2 * p.b2 + (long long)n0 * p.bn;
-    float* C = p.C + z1 * p.c1 + z2 * p.c2;
-    const int ks = ((p.K + p.nsplit - 1) / p.nsplit + 63) / 64 * 64;
+    const int bz = blockIdx.z / p.nsplit, sp = blockIdx.z - bz * p.nsplit;
+    const int z1 = bz / p.nb2, z2 = bz - z1 * p.nb2;
+    const int ks = ((p.K + p.nsplit - 1) / p.nsplit + GM_BK - 1) / GM_BK * GM_BK;
     const int kbeg = sp * ks, kend = min(p.K, kbeg + ks);
-    if (kbeg >= kend) return;                               // uniform per work-group (mode 2 accumulates: nothing to add)
-    const int mleft = p.M - m0, nleft = p.N - n0;
+    if (kbeg >= kend) return;
+    const float* A = p.A + z1 * p.a1 + z2 * p.a2 + (long long)m0 * p.am + (long long)kbeg * p.ak;
+    const float* B = p.B + z1 * p.b1 + z2 * p.b2 + (long long)n0 * p.bn + (long long)kbeg * p.bk;
+    constexpr int QK = GM_BK / 4;
+    const int kg = (tid & 7) + 8 * ((tid >> 6) & 1), mq = ((tid >> 3) & 7) + 8 * (tid >> 7);
+    unsigned offA[GM_NV], offB[GM_NV];
+#pragma unroll
+    for (int q = 0; q < GM_NV; ++q) {
+        const int f = tid + 256 * q;
+        offA[q] = AKC ? (unsigned)((f / QK) * (int)p.am + 4 * (f % QK)) : (unsigned)((GM_NV * kg + q) * (int)p.ak + 4 * mq);
+        offB[q] = BKC ? (unsigned)((f / QK) * (int)p.bn + 4 * (f % QK)) : (unsigned)((GM_NV * kg + q) * (int)p.bk + 4 * mq);
+    }
+    const long long stepA = (long long)GM_BK * p.ak, stepB = (long long)GM_BK * p.bk;
+    float4 va[GM_NV], vb[GM_NV];
+    auto load = [&]() {
+#pragma unroll
+        for (int q = 0; q < GM_NV; ++q) {
+            const f4u a = *reinterpret_cast<const f4u*>(A + offA[q]);
+            const f4u b = *reinterpret_cast<const f4u*>(B + offB[q]);
+            va[q] = make_float4(a[0], a[1], a[2], a[3]);
+            vb[q] = make_float4(b[0], b[1], b[2], b[3]);
+        }
+    };
     f32x16 acc = zero16();
-    float4 va[4], vb[4];
-    gm_load<AKC>(A + (long long)kbeg * p.ak, p.am, p.ak, mleft, kend - kbeg, vecA != 0, tid, va);
-    gm_load<BKC>(B + (long long)kbeg * p.bk, p.bn, p.bk, nleft, kend - kbeg, vecB != 0, tid, vb);
-    for (int k0 = kbeg; k0 < kend; k0 += 64) {
+    const int nsteps = (kend - kbeg) / GM_BK;
+    load();
+    for (int it = 0; it < nsteps; ++it) {
         gm_store<TERMS, AKC>(As, tid, va);
         gm_store<TERMS, BKC>(Bs, tid, vb);
         __syncthreads();
-        if (k0 + 64 < kend) {
-            gm_load<AKC>(A + (long long)(k0 + 64) * p.ak, p.am, p.ak, mleft, kend - k0 - 64, vecA != 0, tid, va);
-            gm_load<BKC>(B + (long long)(k0 + 64) * p.bk, p.bn, p.bk, nleft, kend - k0 - 64, vecB != 0, tid, vb);
-        }
+        if (it + 1 < nsteps) { A += stepA; B += stepB; load(); }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < GM_BK / 16; ++c) {
             const int ko = c * 16 + 8 * (lane >> 5);
             const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&As[0][wm * 32 + (lane & 31)][ko]);
             const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bs[0][wn * 32 + (lane & 31)][ko]);
@@ -148,40 +310,66 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmP p, const int vecA, con
         __syncthreads();
     }
     const int col = n0 + wn * 32 + (lane & 31);
-    if (col >= p.N) return;
     const float bv = (p.bias && sp == 0) ? p.bias[col] : 0.f;
+    float* d0 = p.C + z1 * p.c1 + z2 * p.c2 + (long long)(m0 + wm * 32 + 4 * (lane >> 5)) * p.cm + (long long)col * p.cn;
+    if (p.mode == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 32 + acc_row(r, lane);
-        if (row >= p.M) continue;
-        float* d = C + (long long)row * p.cm + (long long)col * p.cn;
-        const float t = acc[r];
-        const float v = t * p.alpha + bv;
-        if (p.mode == 0) *d = v;
-        else if (p.mode == 1) *d += v;
-        else atomicAdd(d, v);
+        for (int r = 0; r < 16; ++r) d0[(long long)((r & 3) + 8 * (r >> 2)) * p.cm] = acc[r] * p.alpha + bv;
+    } else if (p.mode == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d0[(long long)((r & 3) + 8 * (r >> 2)) * p.cm] += acc[r] * p.alpha + bv;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) atomicAdd(d0 + (long long)((r & 3) + 8 * (r >> 2)) * p.cm, acc[r] * p.alpha + bv);
     }
+}
+template <int TERMS>
+static void launch_gemm_fast_t(hipStream_t st, const GemmP& p, dim3 grid, bool akc, bool bkc) {
+    if (akc && bkc) hipLaunchKernelGGL((k_gemm_fast<TERMS, true, true>), grid, dim3(256), 0, st, p);
+    else if (akc) hipLaunchKernelGGL((k_gemm_fast<TERMS, true, false>), grid, dim3(256), 0, st, p);
+    else if (bkc) hipLaunchKernelGGL((k_gemm_fast<TERMS, false, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm_fast<TERMS, false, false>), grid, dim3(256), 0, st, p);
 }
 
 template <int TERMS>
-static void launch_gemm_t(hipStream_t st, const GemmP& p, dim3 grid, bool akc, bool bkc, int vecA, int vecB) {
-    if (akc && bkc) hipLaunchKernelGGL((k_gemm<TERMS, true, true>), grid, dim3(256), 0, st, p, vecA, vecB);
-    else if (akc) hipLaunchKernelGGL((k_gemm<TERMS, true, false>), grid, dim3(256), 0, st, p, vecA, vecB);
-    else if (bkc) hipLaunchKernelGGL((k_gemm<TERMS, false, true>), grid, dim3(256), 0, st, p, vecA, vecB);
-    else hipLaunchKernelGGL((k_gemm<TERMS, false, false>), grid, dim3(256), 0, st, p, vecA, vecB);
+static void launch_gemm_t(hipStream_t st, const GemmP& p, dim3 grid, bool akc, bool bkc, int vecA, int vecB, int total) {
+    if (akc && bkc) hipLaunchKernelGGL((k_gemm<TERMS, true, true>), grid, dim3(256), 0, st, p, vecA, vecB, total);
+    else if (akc) hipLaunchKernelGGL((k_gemm<TERMS, true, false>), grid, dim3(256), 0, st, p, vecA, vecB, total);
+    else if (bkc) hipLaunchKernelGGL((k_gemm<TERMS, false, true>), grid, dim3(256), 0, st, p, vecA, vecB, total);
+    else hipLaunchKernelGGL((k_gemm<TERMS, false, false>), grid, dim3(256), 0, st, p, vecA, vecB, total);
 }
 // terms: bf16 pieces per operand -- 1: plain bf16 (one MFMA per product), 2: 16 significand bits (three MFMAs), 3: 24 bits (six)
 void launch_gemm(hipStream_t st, const GemmP& p, int terms) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.batch <= 0) return;
-    const dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, p.batch * p.nsplit);
+    {   // the fast path
+        const bool ua = p.ak == 1 || p.am == 1, ub = p.bk == 1 || p.bn == 1;
+        const long long ks = ((p.K + p.nsplit - 1) / p.nsplit + GM_BK - 1) / GM_BK * GM_BK;
+        const long long lim = 1LL << 24;              // a lane offset is at most 64 rows (or GM_BK k) of such a stride
+        static const bool off = getenv("GENIE_GEMM_GENERIC") != nullptr;
+        if (!off && ua && ub && p.M % 64 == 0 && p.N % 64 == 0 && p.K % GM_BK == 0 && ks % GM_BK == 0 && p.am < lim && p.ak < lim && p.bk < lim &&
+            p.bn < lim && (long long)p.batch * p.nsplit < 65536 && p.M / 64 < 65536) {
+            const dim3 grid(p.N / 64, p.M / 64, p.batch * p.nsplit);
+            const bool akc = p.ak == 1, bkc = p.bk == 1;
+            if (terms <= 1) launch_gemm_fast_t<1>(st, p, grid, akc, bkc);
+            else if (terms == 2) launch_gemm_fast_t<2>(st, p, grid, akc, bkc);
+            else launch_gemm_fast_t<3>(st, p, grid, akc, bkc);
+            return;
+        }
+    }
+    const long long tiles = (long long)((p.N + 63) / 64) * ((p.M + 63) / 64) * p.batch * p.nsplit;
+    const int total = (int)tiles;
+    const int wgs_per_cu = GM_WPS;                      // what __launch_bounds__ and the LDS tiles admit per CU
+    long long g = tiles < 256LL * wgs_per_cu ? tiles : 256LL * wgs_per_cu;
+    g = (g + 7) / 8 * 8;
+    const dim3 grid((unsigned)g);
     // lanes walk k unless the row index is the operand's only unit stride
     const bool akc = p.ak == 1 || p.am != 1, bkc = p.bk == 1 || p.bn != 1;
     auto mult4 = [](long long v) { return (v & 3) == 0; };
     const int vecA = ((akc ? p.ak == 1 : p.am == 1) && mult4(akc ? p.am : p.ak) && mult4(p.a1) && mult4(p.a2) && ((uintptr_t)p.A & 15) == 0) ? 1 : 0;
     const int vecB = ((bkc ? p.bk == 1 : p.bn == 1) && mult4(bkc ? p.bn : p.bk) && mult4(p.b1) && mult4(p.b2) && ((uintptr_t)p.B & 15) == 0) ? 1 : 0;
-    if (terms <= 1) launch_gemm_t<1>(st, p, grid, akc, bkc, vecA, vecB);
-    else if (terms == 2) launch_gemm_t<2>(st, p, grid, akc, bkc, vecA, vecB);
-    else launch_gemm_t<3>(st, p, grid, akc, bkc, vecA, vecB);
+    if (terms <= 1) launch_gemm_t<1>(st, p, grid, akc, bkc, vecA, vecB, total);
+    else if (terms == 2) launch_gemm_t<2>(st, p, grid, akc, bkc, vecA, vecB, total);
+    else launch_gemm_t<3>(st, p, grid, akc, bkc, vecA, vecB, total);
 }
 // split-K factor for a reduction of length K into `tiles` output tiles (x batch): enough work-groups to fill the chip, at least 128 of
 // K each.  Only for mode 2 (atomic accumulation).
