@@ -134,8 +134,8 @@ struct Run {
     void lin_bwd_w(const float* dY, long long R, int O, const float* X, long long ldx, int K, size_t w, long long b_off) {
         if (!G) return;                     // input-gradient only (genie_denoise_vjp)
         GemmP p{dY, X, G + w, nullptr, O, K, (int)R, 1, O, ldx, 1, K, 1, 1, 1, 0, 0, 0, 0, 0, 0, gemm_splits(O, K, R, 1), 1.0f, 2};
+        p.asum = b_off >= 0 ? G + b_off : nullptr;      // db: the column sums of dY, taken while the GEMM streams it
         gemm(p);
-        if (b_off >= 0 && !dry) launch_colsum(st, dY, nullptr, R, O, G + b_off, nullptr);
     }
     void ln_fwd(const float* x, size_t g, size_t b, float* y, float* xhat, float* rstd, long long R, int C) {
         if (!dry) launch_ln_fwd(st, x, W + g, W + b, y, xhat, rstd, R, C);
@@ -143,8 +143,7 @@ struct Run {
     // dx (+)= LN backward; gamma / beta gradients
     void ln_bwd(const float* dy, const float* xhat, const float* rstd, size_t g, size_t b, float* dx, long long R, int C, bool accumulate) {
         if (dry) return;
-        launch_ln_bwd(st, dy, xhat, rstd, W + g, dx, R, C, accumulate ? 1 : 0);
-        if (G) launch_colsum(st, dy, xhat, R, C, G + b, G + g);
+        launch_ln_bwd(st, dy, xhat, rstd, W + g, dx, R, C, accumulate ? 1 : 0, G ? G + g : nullptr, G ? G + b : nullptr);
     }
     template <class F> void ew(long long n, F f) { if (!dry) launch_ew(st, n, f); }
 };

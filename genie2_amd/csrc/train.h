@@ -12,12 +12,15 @@ struct GemmP {
     int batch, nb2;
     long long a1, a2, b1, b2, c1, c2;
     int nsplit; float alpha; int mode;
+    float* asum;      // optional (batch 1, A dense [K][M] with am == 1): asum[m] += sum_k A[m][k] -- a Linear's bias gradient rides on its
+                      // weight-gradient GEMM, which streams dY anyway
 };
 void launch_gemm(hipStream_t st, const GemmP& p, int terms);
 int gemm_splits(long long M, long long N, long long K, long long batch);
 
 void launch_ln_fwd(hipStream_t st, const float* x, const float* g, const float* b, float* y, float* xhat, float* rstd, long long R, int C);
-void launch_ln_bwd(hipStream_t st, const float* dy, const float* xhat, const float* rstd, const float* g, float* dx, long long R, int C, int accumulate);
+void launch_ln_bwd(hipStream_t st, const float* dy, const float* xhat, const float* rstd, const float* g, float* dx, long long R, int C, int accumulate,
+                   float* dgamma, float* dbeta);
 void launch_colsum(hipStream_t st, const float* a, const float* w, long long R, int C, float* out_b, float* out_g);
 void launch_transpose(hipStream_t st, const float* in, float* out, int B, int R, int C, bool to_cm);
 void launch_pair_features(hipStream_t st, const float* trans, const float* rots, const int8_t* codes, const float* rmask, const uint8_t* fstm,

@@ -281,8 +281,14 @@ __global__ __launch_bounds__(256, GM_WPS) void k_gemm_fast(const GemmP p) {
     };
     f32x16 acc = zero16();
     const int nsteps = (kend - kbeg) / GM_BK;
+    const bool rowsum = !AKC && p.asum != nullptr && blockIdx.x == 0;     // uniform
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
     load();
     for (int it = 0; it < nsteps; ++it) {
+        if (rowsum) {
+#pragma unroll
+            for (int q = 0; q < GM_NV; ++q) { rs[0] += va[q].x; rs[1] += va[q].y; rs[2] += va[q].z; rs[3] += va[q].w; }
+        }
         gm_store<TERMS, AKC>(As, tid, va);
         gm_store<TERMS, BKC>(Bs, tid, vb);
         __syncthreads();
@@ -308,6 +314,18 @@ __global__ __launch_bounds__(256, GM_WPS) void k_gemm_fast(const GemmP p) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
         }
         __syncthreads();
+    }
+    if (rowsum) {     // a thread holds rows 4 mq .. + 3 over its k; the eight lanes tid & 7 of two waves share mq.  The 64 sums meet
+                      // in LDS and leave as ONE full-wave atomic: what an atomic costs at the L2 is its instruction, not its lanes
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { rs[j] += __shfl_xor(rs[j], 1); rs[j] += __shfl_xor(rs[j], 2); rs[j] += __shfl_xor(rs[j], 4); }
+        float* red = reinterpret_cast<float*>(&As[0][0][0]);            // [2][64]; the last step's barrier has passed
+        if ((tid & 7) == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[((tid >> 6) & 1) * 64 + 4 * mq + j] = rs[j];
+        }
+        __syncthreads();
+        if (tid < 64) atomicAdd(p.asum + m0 + tid, red[tid] + red[64 + tid]);
     }
     const int col = n0 + wn * 32 + (lane & 31);
     const float bv = (p.bias && sp == 0) ? p.bias[col] : 0.f;
@@ -339,7 +357,8 @@ static void launch_gemm_t(hipStream_t st, const GemmP& p, dim3 grid, bool akc, b
     else hipLaunchKernelGGL((k_gemm<TERMS, false, false>), grid, dim3(256), 0, st, p, vecA, vecB, total);
 }
 // terms: bf16 pieces per operand -- 1: plain bf16 (one MFMA per product), 2: 16 significand bits (three MFMAs), 3: 24 bits (six)
-void launch_gemm(hipStream_t st, const GemmP& p, int terms) {
+void launch_gemm(hipStream_t st, const GemmP& p_in, int terms) {
+    GemmP p = p_in;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.batch <= 0) return;
     {   // the fast path
         const bool ua = p.ak == 1 || p.am == 1, ub = p.bk == 1 || p.bn == 1;
@@ -350,12 +369,14 @@ void launch_gemm(hipStream_t st, const GemmP& p, int terms) {
             p.bn < lim && (long long)p.batch * p.nsplit < 65536 && p.M / 64 < 65536) {
             const dim3 grid(p.N / 64, p.M / 64, p.batch * p.nsplit);
             const bool akc = p.ak == 1, bkc = p.bk == 1;
+            if (p.asum && (akc || p.batch != 1)) { launch_colsum(st, p.A, nullptr, p.K, p.M, p.asum, nullptr); p.asum = nullptr; }
             if (terms <= 1) launch_gemm_fast_t<1>(st, p, grid, akc, bkc);
             else if (terms == 2) launch_gemm_fast_t<2>(st, p, grid, akc, bkc);
             else launch_gemm_fast_t<3>(st, p, grid, akc, bkc);
             return;
         }
     }
+    if (p.asum) { launch_colsum(st, p.A, nullptr, p.K, p.M, p.asum, nullptr); p.asum = nullptr; }      // the generic kernel does not carry the row sums
     const long long tiles = (long long)((p.N + 63) / 64) * ((p.M + 63) / 64) * p.batch * p.nsplit;
     const int total = (int)tiles;
     const int wgs_per_cu = GM_WPS;                      // what __launch_bounds__ and the LDS tiles admit per CU
@@ -414,32 +435,64 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, con
         }
     }
 }
-// dx = rstd (dy g - mean(dy g) - xhat mean(dy g xhat)); `accumulate`: dx += (residual path already holds a gradient)
+// dx = rstd (dy g - mean(dy g) - xhat mean(dy g xhat)); `accumulate`: dx += (residual path already holds a gradient).
+// dgamma / dbeta (optional): += sum_r dy xhat / sum_r dy -- a block walks rows_per_block rows (a wave every fourth), its lanes keep
+// their columns' sums in registers, the four waves meet in LDS and the block adds once per column: no second pass over dy and xhat.
 __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ rstd,
-                                                const float* __restrict__ g, float* __restrict__ dx, long long R, int C, int accumulate) {
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= R) return;
-    float t[8], xh[8];
-    float s1 = 0.f, s2 = 0.f;
+                                                const float* __restrict__ g, float* __restrict__ dx, long long R, int C, int accumulate,
+                                                int rows_per_block, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[2][4][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+    float ag[8], ab[8], gv[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int c = lane + 64 * q;
-        t[q] = c < C ? dy[row * C + c] * g[c] : 0.f;
-        xh[q] = c < C ? xhat[row * C + c] : 0.f;
-        s1 += t[q]; s2 += t[q] * xh[q];
-    }
+    for (int q = 0; q < 8; ++q) { ag[q] = 0.f; ab[q] = 0.f; const int c = lane + 64 * q; gv[q] = c < C ? g[c] : 0.f; }
+    // two rows per iteration (rows wave and wave + 4 of an eight-row group): twice the loads in flight
+    for (long long rb = r0 + wave; rb < r1; rb += 8) {
+        float t[2][8], xh[2][8], s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-    s1 /= (float)C; s2 /= (float)C;
-    const float rs = rstd[row];
+        for (int u = 0; u < 2; ++u) {
+            const long long row = rb + 4 * u;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int c = lane + 64 * q;
-        if (c < C) {
-            const float v = rs * (t[q] - s1 - xh[q] * s2);
-            if (accumulate) dx[row * C + c] += v; else dx[row * C + c] = v;
+            for (int q = 0; q < 8; ++q) {
+                const int c = lane + 64 * q;
+                const bool ok = c < C && row < r1;
+                const float dv = ok ? dy[row * C + c] : 0.f;
+                xh[u][q] = ok ? xhat[row * C + c] : 0.f;
+                t[u][q] = dv * gv[q];
+                ag[q] += dv * xh[u][q]; ab[q] += dv;
+                s1[u] += t[u][q]; s2[u] += t[u][q] * xh[u][q];
+            }
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s1[0] += __shfl_xor(s1[0], o); s2[0] += __shfl_xor(s2[0], o);
+            s1[1] += __shfl_xor(s1[1], o); s2[1] += __shfl_xor(s2[1], o);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long row = rb + 4 * u;
+            if (row >= r1) continue;
+            const float m1 = s1[u] / (float)C, m2 = s2[u] / (float)C;
+            const float rs = rstd[row];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int c = lane + 64 * q;
+                if (c < C) {
+                    const float v = rs * (t[u][q] - m1 - xh[u][q] * m2);
+                    if (accumulate) dx[row * C + c] += v; else dx[row * C + c] = v;
+                }
+            }
+        }
+    }
+    if (!dgamma) return;                                    // uniform
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { red[0][wave][lane + 64 * q] = ag[q]; red[1][wave][lane + 64 * q] = ab[q]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
     }
 }
 // column sums over rows: out_b[c] += sum_r a[r,c];  out_g[c] += sum_r a[r,c] w[r,c]   (LayerNorm gamma / beta and Linear bias gradients)
@@ -483,8 +536,11 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ a, con
 void launch_ln_fwd(hipStream_t st, const float* x, const float* g, const float* b, float* y, float* xhat, float* rstd, long long R, int C) {
     hipLaunchKernelGGL(k_ln_fwd, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, x, g, b, y, xhat, rstd, R, C);
 }
-void launch_ln_bwd(hipStream_t st, const float* dy, const float* xhat, const float* rstd, const float* g, float* dx, long long R, int C, int accumulate) {
-    hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, dy, xhat, rstd, g, dx, R, C, accumulate);
+void launch_ln_bwd(hipStream_t st, const float* dy, const float* xhat, const float* rstd, const float* g, float* dx, long long R, int C, int accumulate,
+                   float* dgamma, float* dbeta) {
+    int rpb = (int)((R + 1023) / 1024);                     // about 1024 blocks; a multiple of eight rows each
+    rpb = (rpb + 7) / 8 * 8;
+    hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)((R + rpb - 1) / rpb)), dim3(256), 0, st, dy, xhat, rstd, g, dx, R, C, accumulate, rpb, dgamma, dbeta);
 }
 void launch_colsum(hipStream_t st, const float* a, const float* w, long long R, int C, float* out_b, float* out_g) {
     int rpb = (int)((R + 1023) / 1024);
@@ -759,19 +815,42 @@ __global__ __launch_bounds__(256) void k_ipa_bwd_q(IpaDims d, const float* __res
     __syncthreads();
     if (tid < 9) dR[(size_t)bi * 9 + tid] += red[tid];
     else if (tid < 12) dT[(size_t)bi * 3 + tid - 9] += red[tid];
-    for (int u = tid; u < H * N; u += 256) {          // d att
-        const int h = u / N, j = u % N;
-        const size_t mj = (size_t)b * N + j;
-        float s = 0.f;
-        const float* vr = kv + (mj * H + h) * 2 * C + C;
-        for (int c = 0; c < C; ++c) s += sdo[h * C + c] * vr[c];
-        const float* vpr = vp + (mj * H + h) * Pv * 3;
-        for (int t = 0; t < Pv * 3; ++t) s += sdg[h * Pv * 3 + t] * vpr[t];
-        const float* pr = p + ((size_t)bi * N + j) * cp;
-        for (int c = 0; c < cp; ++c) s += sdop[h * cp + c] * pr[c];
-        dat[u] = s;
+    {   // d att[h][j] = <d o[h], v_j> + <d o_pt[h], v_pt_j> + <d o_pair[h], p[b,i,j,:]>.  The pair rows come through LDS in tiles
+        // of 64 (coalesced; a lane reading its own 512-B row channel by channel touches 64 lines per instruction); thread (j, wave)
+        // accumulates heads wave, wave + 4, ... so that one LDS read of p feeds every head of the thread
+        float* pt = red + 16;               // [64][cp + 1]
+        const int jj = tid & 63, hg = tid >> 6;
+        for (int j0 = 0; j0 < N; j0 += 64) {
+            for (int u = tid; u < 64 * cp; u += 256) {
+                const int r = u / cp, c = u - r * cp;
+                pt[r * (cp + 1) + c] = j0 + r < N ? p[((size_t)bi * N + j0 + r) * cp + c] : 0.f;
+            }
+            __syncthreads();
+            const int j = j0 + jj;
+            if (j < N) {
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                const float* prow = pt + jj * (cp + 1);
+                for (int c = 0; c < cp; ++c) {
+                    const float pv = prow[c];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) if (hg + 4 * t < H) acc[t] += sdop[(hg + 4 * t) * cp + c] * pv;
+                }
+                const size_t mj = (size_t)b * N + j;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int h = hg + 4 * t;
+                    if (h >= H) continue;
+                    float sacc = acc[t];
+                    const float* vr = kv + (mj * H + h) * 2 * C + C;
+                    for (int c = 0; c < C; ++c) sacc += sdo[h * C + c] * vr[c];
+                    const float* vpr = vp + (mj * H + h) * Pv * 3;
+                    for (int q3 = 0; q3 < Pv * 3; ++q3) sacc += sdg[h * Pv * 3 + q3] * vpr[q3];
+                    dat[h * N + j] = sacc;
+                }
+            }
+            __syncthreads();
+        }
     }
-    __syncthreads();
     const float cpt = sqrtf(1.0f / (3.0f * ((float)Pq * 9.0f / 2.0f)));
     {   // d logits = att (d att - sum_j att d att); d head_weights, d bias of linear_b
         const int wave = tid >> 6, lane = tid & 63;
@@ -811,11 +890,25 @@ __global__ __launch_bounds__(256) void k_ipa_bwd_q(IpaDims d, const float* __res
         for (int j = 0; j < N; ++j) s += dat[h * N + j] * (sqp[u] - kp[(((size_t)b * N + j) * H + h) * Pq * 3 + t]);
         dqp[(size_t)bi * H * Pq * 3 + u] = -softplus_dev(head_w[h]) * cpt * s;
     }
-    for (int c = tid; c < cp; c += 256) {             // pair gradient rows (b, i, j, :) += sum_h att do_pair + c_b dlogit W_b
-        for (int j = 0; j < N; ++j) {
-            float s = 0.f;
-            for (int h = 0; h < H; ++h) s += att[h * N + j] * sdop[h * cp + c] + d.c_b * dat[h * N + j] * wb[h * cp + c];
-            dP[((size_t)bi * N + j) * cp + c] += s;
+    // pair gradient rows (b, i, j, :) += sum_h att do_pair + c_b dlogit W_b
+    if (256 % cp == 0 && H <= 16) {         // a thread keeps its channel: its column of d o_pair and W_b stays in registers
+        const int c = tid % cp;
+        float so[16], sw[16];
+#pragma unroll
+        for (int h = 0; h < 16; ++h) { so[h] = h < H ? sdop[h * cp + c] : 0.f; sw[h] = h < H ? d.c_b * wb[h * cp + c] : 0.f; }
+        for (int j = tid / cp; j < N; j += 256 / cp) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int h = 0; h < 16; ++h) if (h < H) sacc += att[h * N + j] * so[h] + dat[h * N + j] * sw[h];
+            dP[((size_t)bi * N + j) * cp + c] += sacc;
+        }
+    } else {
+        for (int c = tid; c < cp; c += 256) {
+            for (int j = 0; j < N; ++j) {
+                float sacc = 0.f;
+                for (int h = 0; h < H; ++h) sacc += att[h * N + j] * sdop[h * cp + c] + d.c_b * dat[h * N + j] * wb[h * cp + c];
+                dP[((size_t)bi * N + j) * cp + c] += sacc;
+            }
         }
     }
 }
@@ -875,9 +968,10 @@ void launch_ipa_fwd(hipStream_t st, const IpaArgs& a) {
 void launch_ipa_bwd(hipStream_t st, const IpaArgs& a) {
     IpaDims d{a.B, a.N, a.H, a.C, a.Pq, a.Pv, a.cp, sqrtf(1.0f / (3.0f * a.C)), sqrtf(1.0f / 3.0f)};
     const size_t lds = ipa_train_lds(a.N, a.H, a.C, a.Pq, a.Pv, a.cp);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_bwd_q), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds_q = lds + (size_t)64 * (a.cp + 1) * sizeof(float);            // + the staged tile of pair rows
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_bwd_q), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_bwd_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_ipa_bwd_q, dim3(a.B * a.N), dim3(256), lds, st, d, a.q, a.kv, a.qp, a.kp, a.vp, a.p, a.rots, a.trans, a.head_w, a.wb,
+    hipLaunchKernelGGL(k_ipa_bwd_q, dim3(a.B * a.N), dim3(256), lds_q, st, d, a.q, a.kv, a.qp, a.kp, a.vp, a.p, a.rots, a.trans, a.head_w, a.wb,
                        a.att, a.cat, a.dcat, a.dlg, a.dq, a.dqp, a.doptg, a.dP, a.dhead, a.dbb, a.dR, a.dT);
     hipLaunchKernelGGL(k_ipa_bwd_k, dim3(a.B * a.N), dim3(256), lds, st, d, a.q, a.qp, a.kp, a.head_w, a.att, a.dlg, a.dcat, a.doptg, a.dkv,
                        a.dkp, a.dvp);
@@ -902,26 +996,44 @@ __global__ void k_points_fwd(const float* __restrict__ lin, const float* __restr
     o[0] = g0; o[1] = g1; o[2] = g2;
 }
 // d lin = R^T d g;  dR[a][c] += dg_a l_c;  dt += dg     (frame gradients through atomics: H P contributions per residue)
-__global__ void k_points_bwd(const float* __restrict__ lin, const float* __restrict__ rots, const float* __restrict__ dg0, const float* __restrict__ dg1,
-                             float* __restrict__ dlin, float* __restrict__ dR, float* __restrict__ dT, int M, int H, int P0, int P1) {
+// one block per residue: its H (P0 + P1) points are reduced in the block (waves by shuffles, then LDS) and the frame gradient is
+// added once -- every point adding to the residue's twelve numbers atomically serialises at the L2
+__global__ __launch_bounds__(256) void k_points_bwd(const float* __restrict__ lin, const float* __restrict__ rots, const float* __restrict__ dg0,
+                                                    const float* __restrict__ dg1, float* __restrict__ dlin, float* __restrict__ dR,
+                                                    float* __restrict__ dT, int M, int H, int P0, int P1) {
+    __shared__ float red[4][12];
     const int PT = P0 + P1;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)M * H * PT) return;
-    const int pt = (int)(idx % PT), h = (int)((idx / PT) % H);
-    const long long m = idx / ((long long)PT * H);
-    const float* g = pt < P0 ? dg0 + ((m * H + h) * P0 + pt) * 3 : dg1 + ((m * H + h) * P1 + (pt - P0)) * 3;
-    const float g0 = g[0], g1 = g[1], g2 = g[2];
+    const long long m = blockIdx.x;
     const float* R = rots + m * 9;
-    const long long lo = m * 3 * H * PT + h * PT + pt;
-    const float l0 = lin[lo], l1 = lin[lo + H * PT], l2 = lin[lo + 2 * H * PT];
-    dlin[lo] = R[0] * g0 + R[3] * g1 + R[6] * g2;
-    dlin[lo + H * PT] = R[1] * g0 + R[4] * g1 + R[7] * g2;
-    dlin[lo + 2 * H * PT] = R[2] * g0 + R[5] * g1 + R[8] * g2;
-    float* r = dR + m * 9;
-    atomicAdd(r + 0, g0 * l0); atomicAdd(r + 1, g0 * l1); atomicAdd(r + 2, g0 * l2);
-    atomicAdd(r + 3, g1 * l0); atomicAdd(r + 4, g1 * l1); atomicAdd(r + 5, g1 * l2);
-    atomicAdd(r + 6, g2 * l0); atomicAdd(r + 7, g2 * l1); atomicAdd(r + 8, g2 * l2);
-    atomicAdd(dT + m * 3, g0); atomicAdd(dT + m * 3 + 1, g1); atomicAdd(dT + m * 3 + 2, g2);
+    float a[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) a[t] = 0.f;
+    for (int u = threadIdx.x; u < H * PT; u += 256) {
+        const int pt = u % PT, h = u / PT;
+        const float* g = pt < P0 ? dg0 + ((m * H + h) * P0 + pt) * 3 : dg1 + ((m * H + h) * P1 + (pt - P0)) * 3;
+        const float g0 = g[0], g1 = g[1], g2 = g[2];
+        const long long lo = m * 3 * H * PT + h * PT + pt;
+        const float l0 = lin[lo], l1 = lin[lo + H * PT], l2 = lin[lo + 2 * H * PT];
+        dlin[lo] = R[0] * g0 + R[3] * g1 + R[6] * g2;
+        dlin[lo + H * PT] = R[1] * g0 + R[4] * g1 + R[7] * g2;
+        dlin[lo + 2 * H * PT] = R[2] * g0 + R[5] * g1 + R[8] * g2;
+        a[0] += g0 * l0; a[1] += g0 * l1; a[2] += g0 * l2;
+        a[3] += g1 * l0; a[4] += g1 * l1; a[5] += g1 * l2;
+        a[6] += g2 * l0; a[7] += g2 * l1; a[8] += g2 * l2;
+        a[9] += g0; a[10] += g1; a[11] += g2;
+    }
+#pragma unroll
+    for (int t = 0; t < 12; ++t)
+        for (int o = 32; o > 0; o >>= 1) a[t] += __shfl_xor(a[t], o);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int t = 0; t < 12; ++t) red[threadIdx.x >> 6][t] = a[t];
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (threadIdx.x < 9) dR[m * 9 + threadIdx.x] += v; else dT[m * 3 + threadIdx.x - 9] += v;
+    }
 }
 void launch_points_fwd(hipStream_t st, const float* lin, const float* rots, const float* trans, float* out0, float* out1, int M, int H, int P0, int P1) {
     const long long n = (long long)M * H * (P0 + P1);
@@ -929,8 +1041,7 @@ void launch_points_fwd(hipStream_t st, const float* lin, const float* rots, cons
 }
 void launch_points_bwd(hipStream_t st, const float* lin, const float* rots, const float* dg0, const float* dg1, float* dlin, float* dR, float* dT,
                        int M, int H, int P0, int P1) {
-    const long long n = (long long)M * H * (P0 + P1);
-    hipLaunchKernelGGL(k_points_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, lin, rots, dg0, dg1, dlin, dR, dT, M, H, P0, P1);
+    hipLaunchKernelGGL(k_points_bwd, dim3((unsigned)M), dim3(256), 0, st, lin, rots, dg0, dg1, dlin, dR, dT, M, H, P0, P1);
 }
 
 // BackboneUpdate + compose (backbone_update.py:40-66, affine_utils.py:109-116, 299-334):
