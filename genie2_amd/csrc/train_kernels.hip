@@ -100,8 +100,8 @@ __device__ __forceinline__ void gm_load(const float* __restrict__ base, long lon
     }
 }
 // NP consecutive k of one row: split into the bf16 pieces, one packed LDS store per piece
-template <int TERMS, int NP>
-__device__ __forceinline__ void gm_put(__bf16 (*S)[64][GM_LD], int row, int k, const float (&x)[NP]) {
+template <int TERMS, int NP, int ROWS = 64>
+__device__ __forceinline__ void gm_put(__bf16 (*S)[ROWS][GM_LD], int row, int k, const float (&x)[NP]) {
     typedef __bf16 vec_t __attribute__((ext_vector_type(NP)));
     vec_t h, m, l;
 #pragma unroll
@@ -118,25 +118,25 @@ __device__ __forceinline__ void gm_put(__bf16 (*S)[64][GM_LD], int row, int k, c
     if (TERMS > 1) *reinterpret_cast<vec_t*>(&S[1][row][k]) = m;
     if (TERMS > 2) *reinterpret_cast<vec_t*>(&S[2][row][k]) = l;
 }
-template <int TERMS, bool KC>
-__device__ __forceinline__ void gm_store(__bf16 (*S)[64][GM_LD], int tid, const float4 (&v)[GM_NV]) {
+template <int TERMS, bool KC, int ROWS = 64>
+__device__ __forceinline__ void gm_store(__bf16 (*S)[ROWS][GM_LD], int tid, const float4 (&v)[GM_NV]) {
     if (KC) {
         constexpr int QK = GM_BK / 4;
 #pragma unroll
         for (int q = 0; q < GM_NV; ++q) {
-            const int f = tid + 256 * q;
+            const int f = tid + 4 * ROWS * q;               // 4 ROWS threads
             const float x[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-            gm_put<TERMS, 4>(S, f / QK, 4 * (f % QK), x);
+            gm_put<TERMS, 4, ROWS>(S, f / QK, 4 * (f % QK), x);
         }
     } else {
         const int kg = (tid & 7) + 8 * ((tid >> 6) & 1), mq = ((tid >> 3) & 7) + 8 * (tid >> 7);
         float x0[GM_NV], x1[GM_NV], x2[GM_NV], x3[GM_NV];
 #pragma unroll
         for (int i = 0; i < GM_NV; ++i) { x0[i] = v[i].x; x1[i] = v[i].y; x2[i] = v[i].z; x3[i] = v[i].w; }
-        gm_put<TERMS, GM_NV>(S, 4 * mq + 0, GM_NV * kg, x0);
-        gm_put<TERMS, GM_NV>(S, 4 * mq + 1, GM_NV * kg, x1);
-        gm_put<TERMS, GM_NV>(S, 4 * mq + 2, GM_NV * kg, x2);
-        gm_put<TERMS, GM_NV>(S, 4 * mq + 3, GM_NV * kg, x3);
+        gm_put<TERMS, GM_NV, ROWS>(S, 4 * mq + 0, GM_NV * kg, x0);
+        gm_put<TERMS, GM_NV, ROWS>(S, 4 * mq + 1, GM_NV * kg, x1);
+        gm_put<TERMS, GM_NV, ROWS>(S, 4 * mq + 2, GM_NV * kg, x2);
+        gm_put<TERMS, GM_NV, ROWS>(S, 4 * mq + 3, GM_NV * kg, x3);
     }
 }
 
@@ -341,6 +341,127 @@ __global__ __launch_bounds__(256, GM_WPS) void k_gemm_fast(const GemmP p) {
         for (int r = 0; r < 16; ++r) atomicAdd(d0 + (long long)((r & 3) + 8 * (r >> 2)) * p.cm, acc[r] * p.alpha + bv);
     }
 }
+// ---- the same for M and N multiples of 128: a 128 x 128 tile per 512-thread work-group, eight waves of 32 x 64 (two accumulators).
+// Per MFMA half the split arithmetic and LDS stores of the 64 x 64 tile and three quarters of its fragment reads; A is read once for
+// N = 128.  60 KiB of LDS: two work-groups = sixteen waves per CU, as before.
+template <int TERMS, bool AKC, bool BKC>
+__global__ __launch_bounds__(512, 4) void k_gemm_big(const GemmP p) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[TERMS][128][GM_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[TERMS][128][GM_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * 128, m0 = blockIdx.y * 128;
+    const int bz = blockIdx.z / p.nsplit, sp = blockIdx.z - bz * p.nsplit;
+    const int z1 = bz / p.nb2, z2 = bz - z1 * p.nb2;
+    const int ks = ((p.K + p.nsplit - 1) / p.nsplit + GM_BK - 1) / GM_BK * GM_BK;
+    const int kbeg = sp * ks, kend = min(p.K, kbeg + ks);
+    if (kbeg >= kend) return;
+    const float* A = p.A + z1 * p.a1 + z2 * p.a2 + (long long)m0 * p.am + (long long)kbeg * p.ak;
+    const float* B = p.B + z1 * p.b1 + z2 * p.b2 + (long long)n0 * p.bn + (long long)kbeg * p.bk;
+    constexpr int QK = GM_BK / 4;
+    const int kg = (tid & 7) + 8 * ((tid >> 6) & 1), mq = ((tid >> 3) & 7) + 8 * (tid >> 7);       // mq 0 .. 31
+    unsigned offA[GM_NV], offB[GM_NV];
+#pragma unroll
+    for (int q = 0; q < GM_NV; ++q) {
+        const int f = tid + 512 * q;
+        offA[q] = AKC ? (unsigned)((f / QK) * (int)p.am + 4 * (f % QK)) : (unsigned)((GM_NV * kg + q) * (int)p.ak + 4 * mq);
+        offB[q] = BKC ? (unsigned)((f / QK) * (int)p.bn + 4 * (f % QK)) : (unsigned)((GM_NV * kg + q) * (int)p.bk + 4 * mq);
+    }
+    const long long stepA = (long long)GM_BK * p.ak, stepB = (long long)GM_BK * p.bk;
+    float4 va[GM_NV], vb[GM_NV];
+    auto load = [&]() {
+#pragma unroll
+        for (int q = 0; q < GM_NV; ++q) {
+            const f4u a = *reinterpret_cast<const f4u*>(A + offA[q]);
+            const f4u b = *reinterpret_cast<const f4u*>(B + offB[q]);
+            va[q] = make_float4(a[0], a[1], a[2], a[3]);
+            vb[q] = make_float4(b[0], b[1], b[2], b[3]);
+        }
+    };
+    f32x16 acc0 = zero16(), acc1 = zero16();
+    const int nsteps = (kend - kbeg) / GM_BK;
+    const bool rowsum = !AKC && p.asum != nullptr && blockIdx.x == 0;     // uniform
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    load();
+    for (int it = 0; it < nsteps; ++it) {
+        if (rowsum) {
+#pragma unroll
+            for (int q = 0; q < GM_NV; ++q) { rs[0] += va[q].x; rs[1] += va[q].y; rs[2] += va[q].z; rs[3] += va[q].w; }
+        }
+        gm_store<TERMS, AKC, 128>(As, tid, va);
+        gm_store<TERMS, BKC, 128>(Bs, tid, vb);
+        __syncthreads();
+        if (it + 1 < nsteps) { A += stepA; B += stepB; load(); }
+#pragma unroll
+        for (int c = 0; c < GM_BK / 16; ++c) {
+            const int ko = c * 16 + 8 * (lane >> 5);
+            const int ar = wm * 32 + (lane & 31), br = wn * 64 + (lane & 31);
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&As[0][ar][ko]);
+            const bf16x8 b0h = *reinterpret_cast<const bf16x8*>(&Bs[0][br][ko]);
+            const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(&Bs[0][br + 32][ko]);
+            if (TERMS > 1) {     // small terms first
+                const bf16x8 am = *reinterpret_cast<const bf16x8*>(&As[TERMS > 1 ? 1 : 0][ar][ko]);
+                const bf16x8 b0m = *reinterpret_cast<const bf16x8*>(&Bs[TERMS > 1 ? 1 : 0][br][ko]);
+                const bf16x8 b1m = *reinterpret_cast<const bf16x8*>(&Bs[TERMS > 1 ? 1 : 0][br + 32][ko]);
+                if (TERMS > 2) {
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&As[TERMS > 2 ? 2 : 0][ar][ko]);
+                    const bf16x8 b0l = *reinterpret_cast<const bf16x8*>(&Bs[TERMS > 2 ? 2 : 0][br][ko]);
+                    const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(&Bs[TERMS > 2 ? 2 : 0][br + 32][ko]);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b0h, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b1h, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0l, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1l, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b0m, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b1m, acc1, 0, 0, 0);
+                }
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b0h, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b1h, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0m, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1m, acc1, 0, 0, 0);
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0h, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1h, acc1, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    if (rowsum) {     // as in k_gemm_fast: 128 sums, two contributing waves each
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { rs[j] += __shfl_xor(rs[j], 1); rs[j] += __shfl_xor(rs[j], 2); rs[j] += __shfl_xor(rs[j], 4); }
+        float* red = reinterpret_cast<float*>(&As[0][0][0]);            // [2][128]
+        if ((tid & 7) == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[((tid >> 6) & 1) * 128 + 4 * mq + j] = rs[j];
+        }
+        __syncthreads();
+        if (tid < 128) atomicAdd(p.asum + m0 + tid, red[tid] + red[128 + tid]);
+    }
+    float* dbase = p.C + z1 * p.c1 + z2 * p.c2 + (long long)(m0 + wm * 32 + 4 * (lane >> 5)) * p.cm;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const f32x16& acc = half ? acc1 : acc0;
+        const int col = n0 + wn * 64 + 32 * half + (lane & 31);
+        const float bv = (p.bias && sp == 0) ? p.bias[col] : 0.f;
+        float* d0 = dbase + (long long)col * p.cn;
+        if (p.mode == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d0[(long long)((r & 3) + 8 * (r >> 2)) * p.cm] = acc[r] * p.alpha + bv;
+        } else if (p.mode == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d0[(long long)((r & 3) + 8 * (r >> 2)) * p.cm] += acc[r] * p.alpha + bv;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) atomicAdd(d0 + (long long)((r & 3) + 8 * (r >> 2)) * p.cm, acc[r] * p.alpha + bv);
+        }
+    }
+}
+template <int TERMS>
+static void launch_gemm_big_t(hipStream_t st, const GemmP& p, dim3 grid, bool akc, bool bkc) {
+    if (akc && bkc) hipLaunchKernelGGL((k_gemm_big<TERMS, true, true>), grid, dim3(512), 0, st, p);
+    else if (akc) hipLaunchKernelGGL((k_gemm_big<TERMS, true, false>), grid, dim3(512), 0, st, p);
+    else if (bkc) hipLaunchKernelGGL((k_gemm_big<TERMS, false, true>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm_big<TERMS, false, false>), grid, dim3(512), 0, st, p);
+}
+
 template <int TERMS>
 static void launch_gemm_fast_t(hipStream_t st, const GemmP& p, dim3 grid, bool akc, bool bkc) {
     if (akc && bkc) hipLaunchKernelGGL((k_gemm_fast<TERMS, true, true>), grid, dim3(256), 0, st, p);
@@ -367,9 +488,18 @@ void launch_gemm(hipStream_t st, const GemmP& p_in, int terms) {
         static const bool off = getenv("GENIE_GEMM_GENERIC") != nullptr;
         if (!off && ua && ub && p.M % 64 == 0 && p.N % 64 == 0 && p.K % GM_BK == 0 && ks % GM_BK == 0 && p.am < lim && p.ak < lim && p.bk < lim &&
             p.bn < lim && (long long)p.batch * p.nsplit < 65536 && p.M / 64 < 65536) {
-            const dim3 grid(p.N / 64, p.M / 64, p.batch * p.nsplit);
             const bool akc = p.ak == 1, bkc = p.bk == 1;
             if (p.asum && (akc || p.batch != 1)) { launch_colsum(st, p.A, nullptr, p.K, p.M, p.asum, nullptr); p.asum = nullptr; }
+            static const bool nobig = getenv("GENIE_GEMM_NO_BIG") != nullptr;
+            const long long big_tiles = (long long)(p.M / 128) * (p.N / 128) * p.batch * p.nsplit;
+            if (!nobig && p.M % 128 == 0 && p.N % 128 == 0 && big_tiles >= 256) {
+                const dim3 gb(p.N / 128, p.M / 128, p.batch * p.nsplit);
+                if (terms <= 1) launch_gemm_big_t<1>(st, p, gb, akc, bkc);
+                else if (terms == 2) launch_gemm_big_t<2>(st, p, gb, akc, bkc);
+                else launch_gemm_big_t<3>(st, p, gb, akc, bkc);
+                return;
+            }
+            const dim3 grid(p.N / 64, p.M / 64, p.batch * p.nsplit);
             if (terms <= 1) launch_gemm_fast_t<1>(st, p, grid, akc, bkc);
             else if (terms == 2) launch_gemm_fast_t<2>(st, p, grid, akc, bkc);
             else launch_gemm_fast_t<3>(st, p, grid, akc, bkc);
