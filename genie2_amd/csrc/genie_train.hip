@@ -121,13 +121,16 @@ struct Run {
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
     // Y[R][O] = X[R][K] (ld ldx) W[O][K]^T + b
-    void lin_fwd(const float* X, long long ldx, long long R, int K, size_t w, long long b_off, int O, float* Y, int mode = 0) {
+    void lin_fwd(const float* X, long long ldx, long long R, int K, size_t w, long long b_off, int O, float* Y, int mode = 0, bool relu = false) {
         GemmP p{X, W + w, Y, b_off >= 0 ? W + b_off : nullptr, (int)R, O, K, ldx, 1, 1, K, O, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0f, mode};
+        p.relu = relu ? 1 : 0;
         gemm(p);
     }
     // dX[R][K] (+)= dY[R][O] W[O][K]
-    void lin_bwd_x(const float* dY, long long R, int O, size_t w, int K, float* dX, long long lddx, bool accumulate) {
+    // `relu_out` (laid out like dX, not with accumulate): the forward ReLU's output -- dX is zeroed where it is not positive
+    void lin_bwd_x(const float* dY, long long R, int O, size_t w, int K, float* dX, long long lddx, bool accumulate, const float* relu_out = nullptr) {
         GemmP p{dY, W + w, dX, nullptr, (int)R, K, O, O, 1, K, 1, lddx, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0f, accumulate ? 1 : 0};
+        p.gate = relu_out;
         gemm(p);
     }
     // dW[O][K] += dY[R][O]^T X[R][K];  db[O] += column sums of dY
@@ -261,8 +264,7 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         size_t mark = T.off;
         float* zn = T.f(P * cp); float* ot = T.f(P * cp);
         r.ln_fwd(z, o.ln_g, o.ln_b, zn, s.xhat, s.rstd, P, cp);
-        r.lin_fwd(zn, cp, P, cp, o.w1, o.b1, nh, s.h);
-        { float* hh = s.h; r.ew(P * nh, [=] __device__(long long e) { hh[e] = fmaxf(hh[e], 0.f); }); }
+        r.lin_fwd(zn, cp, P, cp, o.w1, o.b1, nh, s.h, 0, true);          // Linear + ReLU
         r.lin_fwd(s.h, nh, P, nh, o.w2, o.b2, cp, ot);
         r.ew(P * cp, [=] __device__(long long e) {
             const long long row = e / cp; const int j = (int)(row % N); const long long bi = row / N; const long long b = bi / N;
@@ -310,10 +312,8 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
                 });
             }
             r.ln_fwd(s1, o.ln1_g, o.ln1_b, v.s2, v.xhat1, v.rstd1, M, cs);
-            r.lin_fwd(v.s2, cs, M, cs, o.t1w, o.t1b, cs, v.h1);
-            { float* x = v.h1; r.ew((long long)M * cs, [=] __device__(long long e) { x[e] = fmaxf(x[e], 0.f); }); }
-            r.lin_fwd(v.h1, cs, M, cs, o.t2w, o.t2b, cs, v.h2);
-            { float* x = v.h2; r.ew((long long)M * cs, [=] __device__(long long e) { x[e] = fmaxf(x[e], 0.f); }); }
+            r.lin_fwd(v.s2, cs, M, cs, o.t1w, o.t1b, cs, v.h1, 0, true);       // Linear + ReLU
+            r.lin_fwd(v.h1, cs, M, cs, o.t2w, o.t2b, cs, v.h2, 0, true);
             float* s3 = T.f((size_t)M * cs);
             r.lin_fwd(v.h2, cs, M, cs, o.t3w, o.t3b, cs, s3);
             {
@@ -371,12 +371,10 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         if (!dry) (void)hipMemcpyAsync(d2, d3, (size_t)M * cs * 4, hipMemcpyDeviceToDevice, st);
         r.lin_bwd_w(d3, M, cs, v.h2, cs, cs, o.t3w, (long long)o.t3b);
         float* dh = T.f((size_t)M * cs);
-        r.lin_bwd_x(d3, M, cs, o.t3w, cs, dh, cs, false);
-        { const float* h2 = v.h2; r.ew((long long)M * cs, [=] __device__(long long e) { if (h2[e] <= 0.f) dh[e] = 0.f; }); }
+        r.lin_bwd_x(d3, M, cs, o.t3w, cs, dh, cs, false, v.h2);            // through the ReLU
         r.lin_bwd_w(dh, M, cs, v.h1, cs, cs, o.t2w, (long long)o.t2b);
         float* dh1 = d3;        // reuse
-        r.lin_bwd_x(dh, M, cs, o.t2w, cs, dh1, cs, false);
-        { const float* h1 = v.h1; r.ew((long long)M * cs, [=] __device__(long long e) { if (h1[e] <= 0.f) dh1[e] = 0.f; }); }
+        r.lin_bwd_x(dh, M, cs, o.t2w, cs, dh1, cs, false, v.h1);
         r.lin_bwd_w(dh1, M, cs, v.s2, cs, cs, o.t1w, (long long)o.t1b);
         r.lin_bwd_x(dh1, M, cs, o.t1w, cs, d2, cs, true);
         float* d1 = dh;         // gradient wrt s1 (dropped sum)
@@ -499,8 +497,7 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         });
         r.lin_bwd_w(dot, P, cp, sv.h, nh, nh, o.w2, (long long)o.b2);
         float* dh = T.f(P * nh);
-        r.lin_bwd_x(dot, P, cp, o.w2, nh, dh, nh, false);
-        { const float* hh = sv.h; r.ew(P * nh, [=] __device__(long long e) { if (hh[e] <= 0.f) dh[e] = 0.f; }); }
+        r.lin_bwd_x(dot, P, cp, o.w2, nh, dh, nh, false, sv.h);          // through the ReLU
         float* zn = T.f(P * cp);
         { const float* xh = sv.xhat; const float* gg = Wd + o.ln_g; const float* bb = Wd + o.ln_b;
           r.ew(P * cp, [=] __device__(long long e) { const int c = (int)(e % cp); zn[e] = xh[e] * gg[c] + bb[c]; }); }

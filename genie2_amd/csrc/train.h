@@ -12,6 +12,8 @@ struct GemmP {
     int batch, nb2;
     long long a1, a2, b1, b2, c1, c2;
     int nsplit; float alpha; int mode;
+    int relu;         // mode 0: store max(v, 0)                      (a Linear + ReLU in one pass)
+    const float* gate;  // mode 0: store v where gate > 0, else 0; gate is laid out like C   (ReLU backward on the dX GEMM)
     float* asum;      // optional (batch 1, A dense [K][M] with am == 1): asum[m] += sum_k A[m][k] -- a Linear's bias gradient rides on its
                       // weight-gradient GEMM, which streams dY anyway
 };

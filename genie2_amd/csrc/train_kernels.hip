@@ -217,9 +217,12 @@ __global__ __launch_bounds__(256, GM_WPS) void k_gemm(const GemmP p, const int v
                         const int row = cur.m0 + wm * 32 + acc_row(r, lane);
                         if (row >= p.M) continue;
                         float* d = cur.C + (long long)row * p.cm + (long long)col * p.cn;
-                        const float v = acc[r] * p.alpha + bv;
-                        if (p.mode == 0) *d = v;
-                        else if (p.mode == 1) *d += v;
+                        float v = acc[r] * p.alpha + bv;
+                        if (p.mode == 0) {
+                            if (p.relu) v = fmaxf(v, 0.f);
+                            if (p.gate && !(p.gate[d - p.C] > 0.f)) v = 0.f;
+                            *d = v;
+                        } else if (p.mode == 1) *d += v;
                         else atomicAdd(d, v);
                     }
                 }
@@ -331,8 +334,15 @@ __global__ __launch_bounds__(256, GM_WPS) void k_gemm_fast(const GemmP p) {
     const float bv = (p.bias && sp == 0) ? p.bias[col] : 0.f;
     float* d0 = p.C + z1 * p.c1 + z2 * p.c2 + (long long)(m0 + wm * 32 + 4 * (lane >> 5)) * p.cm + (long long)col * p.cn;
     if (p.mode == 0) {
+        const float* g0 = p.gate ? p.gate + (d0 - p.C) : nullptr;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) d0[(long long)((r & 3) + 8 * (r >> 2)) * p.cm] = acc[r] * p.alpha + bv;
+        for (int r = 0; r < 16; ++r) {
+            const long long o = (long long)((r & 3) + 8 * (r >> 2)) * p.cm;
+            float v = acc[r] * p.alpha + bv;
+            if (p.relu) v = fmaxf(v, 0.f);
+            if (g0 && !(g0[o] > 0.f)) v = 0.f;
+            d0[o] = v;
+        }
     } else if (p.mode == 1) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) d0[(long long)((r & 3) + 8 * (r >> 2)) * p.cm] += acc[r] * p.alpha + bv;
@@ -443,8 +453,15 @@ __global__ __launch_bounds__(512, 4) void k_gemm_big(const GemmP p) {
         const float bv = (p.bias && sp == 0) ? p.bias[col] : 0.f;
         float* d0 = dbase + (long long)col * p.cn;
         if (p.mode == 0) {
+            const float* g0 = p.gate ? p.gate + (d0 - p.C) : nullptr;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d0[(long long)((r & 3) + 8 * (r >> 2)) * p.cm] = acc[r] * p.alpha + bv;
+            for (int r = 0; r < 16; ++r) {
+                const long long o = (long long)((r & 3) + 8 * (r >> 2)) * p.cm;
+                float v = acc[r] * p.alpha + bv;
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (g0 && !(g0[o] > 0.f)) v = 0.f;
+                d0[o] = v;
+            }
         } else if (p.mode == 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) d0[(long long)((r & 3) + 8 * (r >> 2)) * p.cm] += acc[r] * p.alpha + bv;
