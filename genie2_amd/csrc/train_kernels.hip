@@ -835,7 +835,7 @@ void launch_pair_sum_bwd(hipStream_t st, const float* dp, float* dpi, float* dpj
 // (modules/invariant_point_attention.py:100-260).  Row-major inputs straight from the projection GEMMs:
 //   q [M][H C], kv [M][H][2C] (k, then v), global-frame points qp [M][H][Pq][3], kp [M][H][Pq][3], vp [M][H][Pv][3],
 //   bias [B N N][H] = linear_b(p), p [B N N][cp].  One work-group per query (b, i).
-struct IpaDims { int B, N, H, C, Pq, Pv, cp; float c_qk, c_b; };
+struct IpaDims { int B, N, H, C, Pq, Pv, cp; float c_qk, c_b; int skip; };     // skip: developer knock-out mask (GENIE_IPA_SKIP), 0 in use
 __device__ __forceinline__ float softplus_dev(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
 __global__ __launch_bounds__(256) void k_ipa_fwd(IpaDims d, const float* __restrict__ q, const float* __restrict__ kv, const float* __restrict__ qp,
@@ -888,20 +888,45 @@ __global__ __launch_bounds__(256) void k_ipa_fwd(IpaDims d, const float* __restr
     for (int u = tid; u < H * C; u += 256) {          // o
         const int h = u / C, c = u % C;
         float s = 0.f;
+#pragma unroll 8
         for (int j = 0; j < N; ++j) s += att[h * N + j] * kv[(((size_t)b * N + j) * H + h) * 2 * C + C + c];
         crow[u] = s;
     }
     for (int u = tid; u < H * Pv * 3; u += 256) {     // o_pt, global frame
         const int h = u / (Pv * 3), t = u % (Pv * 3);
         float s = 0.f;
+#pragma unroll 8
         for (int j = 0; j < N; ++j) s += att[h * N + j] * vp[(((size_t)b * N + j) * H + h) * Pv * 3 + t];
         sopt[u] = s;
     }
-    for (int u = tid; u < H * cp; u += 256) {         // o_pair
-        const int h = u / cp, c = u % cp;
-        float s = 0.f;
-        for (int j = 0; j < N; ++j) s += att[h * N + j] * p[((size_t)bi * N + j) * cp + c];
-        crow[H * C + 4 * H * Pv + u] = s;
+    if (256 % cp == 0 && H <= 16) {                   // o_pair: a thread keeps its channel and walks every (256 / cp)-th j -- each pair
+        const int c = tid % cp, part = tid / cp, nparts = 256 / cp;       // row is read once, for all heads; the parts meet in LDS
+        float* spart = sopt + H * Pv * 3;             // [nparts][H][cp]
+        float acc[16];
+#pragma unroll
+        for (int h = 0; h < 16; ++h) acc[h] = 0.f;
+#pragma unroll 8
+        for (int j = part; j < N; j += nparts) {
+            const float pv = p[((size_t)bi * N + j) * cp + c];
+#pragma unroll
+            for (int h = 0; h < 16; ++h) if (h < H) acc[h] += att[h * N + j] * pv;
+        }
+#pragma unroll
+        for (int h = 0; h < 16; ++h) if (h < H) spart[(part * H + h) * cp + c] = acc[h];
+        __syncthreads();
+        for (int u = tid; u < H * cp; u += 256) {
+            float sacc = 0.f;
+            for (int q = 0; q < nparts; ++q) sacc += spart[q * H * cp + u];
+            crow[H * C + 4 * H * Pv + u] = sacc;
+        }
+    } else {
+        for (int u = tid; u < H * cp; u += 256) {
+            const int h = u / cp, c = u % cp;
+            float s = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < N; ++j) s += att[h * N + j] * p[((size_t)bi * N + j) * cp + c];
+            crow[H * C + 4 * H * Pv + u] = s;
+        }
     }
     __syncthreads();
     const float* R = rots + (size_t)bi * 9;
@@ -962,12 +987,13 @@ __global__ __launch_bounds__(256) void k_ipa_bwd_q(IpaDims d, const float* __res
     __syncthreads();
     if (tid < 9) dR[(size_t)bi * 9 + tid] += red[tid];
     else if (tid < 12) dT[(size_t)bi * 3 + tid - 9] += red[tid];
-    {   // d att[h][j] = <d o[h], v_j> + <d o_pt[h], v_pt_j> + <d o_pair[h], p[b,i,j,:]>.  The pair rows come through LDS in tiles
+    if (!(d.skip & 1)) {   // d att[h][j] = <d o[h], v_j> + <d o_pt[h], v_pt_j> + <d o_pair[h], p[b,i,j,:]>.  The pair rows come through LDS in tiles
         // of 64 (coalesced; a lane reading its own 512-B row channel by channel touches 64 lines per instruction); thread (j, wave)
         // accumulates heads wave, wave + 4, ... so that one LDS read of p feeds every head of the thread
         float* pt = red + 16;               // [64][cp + 1]
         const int jj = tid & 63, hg = tid >> 6;
         for (int j0 = 0; j0 < N; j0 += 64) {
+#pragma unroll 8
             for (int u = tid; u < 64 * cp; u += 256) {
                 const int r = u / cp, c = u - r * cp;
                 pt[r * (cp + 1) + c] = j0 + r < N ? p[((size_t)bi * N + j0 + r) * cp + c] : 0.f;
@@ -999,7 +1025,7 @@ __global__ __launch_bounds__(256) void k_ipa_bwd_q(IpaDims d, const float* __res
         }
     }
     const float cpt = sqrtf(1.0f / (3.0f * ((float)Pq * 9.0f / 2.0f)));
-    {   // d logits = att (d att - sum_j att d att); d head_weights, d bias of linear_b
+    if (!(d.skip & 2)) {   // d logits = att (d att - sum_j att d att); d head_weights, d bias of linear_b
         const int wave = tid >> 6, lane = tid & 63;
         for (int h = wave; h < H; h += 4) {
             float s = 0.f;
@@ -1025,24 +1051,28 @@ __global__ __launch_bounds__(256) void k_ipa_bwd_q(IpaDims d, const float* __res
         }
     }
     __syncthreads();
-    for (int u = tid; u < H * C; u += 256) {          // dq
+    for (int u = tid; u < ((d.skip & 4) ? 0 : H * C); u += 256) {          // dq
         const int h = u / C, c = u % C;
         float s = 0.f;
+#pragma unroll 8
         for (int j = 0; j < N; ++j) s += dat[h * N + j] * kv[(((size_t)b * N + j) * H + h) * 2 * C + c];
         dq[(size_t)bi * H * C + u] = s * d.c_qk;
     }
-    for (int u = tid; u < H * Pq * 3; u += 256) {     // dq_pts (global): -hw sum_j dlogit (qp - kp_j)
+    for (int u = tid; u < ((d.skip & 8) ? 0 : H * Pq * 3); u += 256) {     // dq_pts (global): -hw sum_j dlogit (qp - kp_j)
         const int h = u / (Pq * 3), t = u % (Pq * 3);
         float s = 0.f;
+#pragma unroll 8
         for (int j = 0; j < N; ++j) s += dat[h * N + j] * (sqp[u] - kp[(((size_t)b * N + j) * H + h) * Pq * 3 + t]);
         dqp[(size_t)bi * H * Pq * 3 + u] = -softplus_dev(head_w[h]) * cpt * s;
     }
     // pair gradient rows (b, i, j, :) += sum_h att do_pair + c_b dlogit W_b
+    if (d.skip & 16) return;
     if (256 % cp == 0 && H <= 16) {         // a thread keeps its channel: its column of d o_pair and W_b stays in registers
         const int c = tid % cp;
         float so[16], sw[16];
 #pragma unroll
         for (int h = 0; h < 16; ++h) { so[h] = h < H ? sdop[h * cp + c] : 0.f; sw[h] = h < H ? d.c_b * wb[h * cp + c] : 0.f; }
+#pragma unroll 8
         for (int j = tid / cp; j < N; j += 256 / cp) {
             float sacc = 0.f;
 #pragma unroll
@@ -1051,6 +1081,7 @@ __global__ __launch_bounds__(256) void k_ipa_bwd_q(IpaDims d, const float* __res
         }
     } else {
         for (int c = tid; c < cp; c += 256) {
+#pragma unroll 8
             for (int j = 0; j < N; ++j) {
                 float sacc = 0.f;
                 for (int h = 0; h < H; ++h) sacc += att[h * N + j] * sdop[h * cp + c] + d.c_b * dat[h * N + j] * wb[h * cp + c];
@@ -1102,18 +1133,20 @@ __global__ __launch_bounds__(256) void k_ipa_bwd_k(IpaDims d, const float* __res
         dvp[(size_t)bj * H * Pv * 3 + u] = s;
     }
 }
+static int ipa_skip() { static const int v = getenv("GENIE_IPA_SKIP") ? atoi(getenv("GENIE_IPA_SKIP")) : 0; return v; }
 size_t ipa_train_lds(int N, int H, int C, int Pq, int Pv, int cp) {
     return (size_t)(2 * H * N + 2 * H * C + H * Pv * 3 + H * cp + H * Pq * 3 + 16) * sizeof(float);
 }
 void launch_ipa_fwd(hipStream_t st, const IpaArgs& a) {
-    IpaDims d{a.B, a.N, a.H, a.C, a.Pq, a.Pv, a.cp, sqrtf(1.0f / (3.0f * a.C)), sqrtf(1.0f / 3.0f)};
-    const size_t lds = ipa_train_lds(a.N, a.H, a.C, a.Pq, a.Pv, a.cp);
+    IpaDims d{a.B, a.N, a.H, a.C, a.Pq, a.Pv, a.cp, sqrtf(1.0f / (3.0f * a.C)), sqrtf(1.0f / 3.0f), ipa_skip()};
+    // the forward kernel lays out att [H N], q, q points, output points, then the o_pair partial sums [256 / cp][H][cp]
+    const size_t lds = (size_t)(a.H * a.N + a.H * a.C + a.H * a.Pq * 3 + a.H * a.Pv * 3 + (a.cp <= 256 && 256 % a.cp == 0 ? (256 / a.cp) * a.H * a.cp : 0)) * sizeof(float);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_ipa_fwd, dim3(a.B * a.N), dim3(256), lds, st, d, a.q, a.kv, a.qp, a.kp, a.vp, a.bias, a.p, a.rots, a.trans, a.rmask,
                        a.head_w, a.att, a.cat);
 }
 void launch_ipa_bwd(hipStream_t st, const IpaArgs& a) {
-    IpaDims d{a.B, a.N, a.H, a.C, a.Pq, a.Pv, a.cp, sqrtf(1.0f / (3.0f * a.C)), sqrtf(1.0f / 3.0f)};
+    IpaDims d{a.B, a.N, a.H, a.C, a.Pq, a.Pv, a.cp, sqrtf(1.0f / (3.0f * a.C)), sqrtf(1.0f / 3.0f), ipa_skip()};
     const size_t lds = ipa_train_lds(a.N, a.H, a.C, a.Pq, a.Pv, a.cp);
     const size_t lds_q = lds + (size_t)64 * (a.cp + 1) * sizeof(float);            // + the staged tile of pair rows
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_bwd_q), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
