@@ -43,6 +43,12 @@ class GenieTaps(C.Structure):
                                               'ipa_cat0')]
 
 
+class GenieGemmDesc(C.Structure):
+    """genie_gemm_desc_t (include/genie_hip.h): one strided, batched GEMM of the training path."""
+    _fields_ = [(n, C.c_int32) for n in ('M', 'N', 'K', 'batch', 'nb2', 'nsplit', 'mode', 'terms', 'relu')] + \
+               [(n, C.c_int64) for n in ('am', 'ak', 'bk', 'bn', 'cm', 'cn', 'a1', 'a2', 'b1', 'b2', 'c1', 'c2')] + [('alpha', C.c_float)]
+
+
 class GenieTrainOpts(C.Structure):
     _fields_ = [('tri_dropout', C.c_float), ('ipa_dropout', C.c_float), ('transition_dropout', C.c_float), ('seed', C.c_uint32),
                 ('train_mode', C.c_int32), ('fast_math', C.c_int32), ('struct_done_event', C.c_void_p)]
@@ -69,6 +75,7 @@ SYMBOLS = {
                                                 C.c_void_p, C.c_float, C.POINTER(GenieTrainOpts), C.c_void_p, C.c_void_p]),
     'genie_denoise_vjp': (C.c_int, [C.c_void_p] * 10),
     'genie_train_workspace_bytes': (C.c_size_t, [C.c_void_p]),
+    'genie_train_gemm': (C.c_int, [C.c_void_p, C.POINTER(GenieGemmDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'genie_p_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p]),
     'genie_sample_loop': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

@@ -596,3 +596,16 @@ int genie_denoise_vjp(genie_handle_t h, genie_stream_t stream, const float* weig
 }
 
 size_t genie_train_workspace_bytes(genie_handle_t h) { return h && h->train ? h->train->kept_bytes + h->train->tmp_bytes : 0; }
+
+int genie_train_gemm(genie_stream_t stream, const genie_gemm_desc_t* q, const float* a, const float* b, float* c, const float* bias,
+                     const float* gate, float* asum) {
+    if (!q || !a || !b || !c || q->M <= 0 || q->N <= 0 || q->K <= 0 || q->batch <= 0 || q->nb2 <= 0 || q->batch % q->nb2 != 0 || q->nsplit <= 0)
+        return -1;
+    if ((q->nsplit > 1 && q->mode != 2) || q->mode < 0 || q->mode > 2) return -1;
+    if (asum && !(q->batch == 1 && q->am == 1 && q->ak == q->M)) return -1;
+    GemmP p{a, b, c, bias, q->M, q->N, q->K, q->am, q->ak, q->bk, q->bn, q->cm, q->cn, q->batch, q->nb2, q->a1, q->a2, q->b1, q->b2, q->c1, q->c2,
+            q->nsplit, q->alpha, q->mode};
+    p.relu = q->relu; p.gate = gate; p.asum = asum;
+    launch_gemm(static_cast<hipStream_t>(stream), p, q->terms);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -239,6 +239,21 @@ int genie_denoise_vjp(genie_handle_t h, genie_stream_t stream, const float* weig
 /* Bytes of activations + scratch the last training call holds. */
 size_t genie_train_workspace_bytes(genie_handle_t h);
 
+/* The training path's building block, exposed so that it can be checked on its own (tests/test_train_gemm.py; the reference has no
+ * counterpart: there these are torch.nn.Linear / einsum calls inside autograd, genie/model/*.py).  Device pointers, element strides:
+ *   C[z][m][n] (op)= alpha * sum_k A[z][m][k] B[z][k][n] (+ bias[n]),   z = z1 * nb2 + z2,  z1 < batch / nb2
+ *   A at a + z1 a1 + z2 a2 + m am + k ak;  B at b + z1 b1 + z2 b2 + k bk + n bn;  C at c + z1 c1 + z2 c2 + m cm + n cn
+ * mode 0 store (then optionally relu, and / or zero where gate <= 0, gate laid out like C), 1 add, 2 atomic add (required for
+ * nsplit > 1 or batches sharing C).  terms: bf16 pieces per f32 operand (1 = bf16 products, 2 = 16 bits, 3 = f32-grade).
+ * asum (optional, batch 1, am == 1, ak == M): asum[m] += sum_k A[m][k].  Returns 0, or -1 for an impossible shape. */
+typedef struct {
+    int32_t M, N, K, batch, nb2, nsplit, mode, terms, relu;
+    int64_t am, ak, bk, bn, cm, cn, a1, a2, b1, b2, c1, c2;
+    float alpha;
+} genie_gemm_desc_t;
+int genie_train_gemm(genie_stream_t stream, const genie_gemm_desc_t* desc, const float* a, const float* b, float* c, const float* bias,
+                     const float* gate, float* asum);
+
 /* ---- measurement ------------------------------------------------------- */
 
 /* Per-kernel-class HIP-event timing on the launch stream (bench.py roofline
