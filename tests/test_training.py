@@ -96,6 +96,30 @@ def _case(seed, lengths, motif=True, chains=None):
     return f, z, g
 
 
+def test_gradients_match_oracle_autograd_base_model_n128():
+    """The base model at N = 128, batch 2 (32768 pair rows, ragged lengths, a motif): the size at which the training step runs the
+    128 x 128-tile GEMM, split-K over hundreds of work-groups with the bias row sums riding along, LayerNorm backward with many rows
+    per block -- none of which the N = 16 cases reach.  Every gradient against torch autograd over the oracle."""
+    from genie2_amd.engine import GenieEngine
+    dims = dict(O.BASE_DIMS)
+    sd = O.synthetic_state_dict(dims, seed=3)
+    f, z, g = _case(11, [128, 101])
+    sched = O.training_schedule(dims['n_timestep'])
+    s = torch.tensor([412, 77])
+    fr = O.prepare_features(f)
+    trans, rots = O.q_sample(f['atom_positions'], s, z, fr['chain_index'], fr['residue_mask'], sched)
+    zo, lo, gref = _oracle_grads(sd, dims, rots, trans, s.int(), f, z, 1.0)
+    eng = GenieEngine(dims, sd, 'cuda:0')
+    eng.bind_features(f)
+    out = eng.train_forward_backward(flat(sd, dims).cuda(), trans, rots, s.int(), z, 1.0, train_mode=False)
+    m = fr['residue_mask'].unsqueeze(-1).float()
+    assert float(((out['z'].cpu() - zo) * m).abs().max()) <= 2e-4 * max(1.0, float(zo.abs().max()))
+    assert abs(float(out['weighted_loss']) - float(lo['weighted_loss'].detach())) <= 1e-4 * float(lo['weighted_loss'].detach())
+    worst = check_grads(split(out['grads'].cpu(), dims), gref)
+    print('worst relative gradient difference', worst)
+    eng.close()
+
+
 @pytest.mark.parametrize('rescale', [1.0, 2.0])
 def test_gradients_match_oracle_autograd_small_dims(rescale):
     """ragged batch, motif conditioning, two chains, odd shapes: every gradient against torch autograd over the oracle"""
