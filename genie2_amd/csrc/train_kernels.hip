@@ -838,24 +838,30 @@ void launch_pair_sum_bwd(hipStream_t st, const float* dp, float* dpi, float* dpj
 struct IpaDims { int B, N, H, C, Pq, Pv, cp; float c_qk, c_b; int skip; };     // skip: developer knock-out mask (GENIE_IPA_SKIP), 0 in use
 __device__ __forceinline__ float softplus_dev(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
-__global__ __launch_bounds__(256) void k_ipa_fwd(IpaDims d, const float* __restrict__ q, const float* __restrict__ kv, const float* __restrict__ qp,
+// The IPA training kernels run one block per (b, i) query or key row -- B N blocks, two per CU at N = 256, batch 2 -- and are bound by
+// the latency of their loops: IPA_NT threads per block decide how many waves a CU has to hide it with.
+#ifndef IPA_NT
+#define IPA_NT 1024
+#endif
+template <int HT>      // head count at compile time (0: d.H) -- the per-head loops are unrolled over registers
+__global__ __launch_bounds__(IPA_NT) void k_ipa_fwd(IpaDims d, const float* __restrict__ q, const float* __restrict__ kv, const float* __restrict__ qp,
                                                  const float* __restrict__ kp, const float* __restrict__ vp, const float* __restrict__ bias,
                                                  const float* __restrict__ p, const float* __restrict__ rots, const float* __restrict__ trans,
                                                  const float* __restrict__ rmask, const float* __restrict__ head_w, float* __restrict__ att_out,
                                                  float* __restrict__ cat) {
     extern __shared__ float sm[];
-    const int N = d.N, H = d.H, C = d.C, Pq = d.Pq, Pv = d.Pv, cp = d.cp;
+    const int N = d.N, H = HT > 0 ? HT : d.H, C = d.C, Pq = d.Pq, Pv = d.Pv, cp = d.cp;
     float* att = sm;                        // [H][N]
     float* sq = att + H * N;                // [H C]
     float* sqp = sq + H * C;                // [H Pq 3]
     float* sopt = sqp + H * Pq * 3;         // [H Pv 3] global-frame output points
     const int bi = blockIdx.x, b = bi / N, i = bi % N, tid = threadIdx.x;
-    for (int u = tid; u < H * C; u += 256) sq[u] = q[(size_t)bi * H * C + u];
-    for (int u = tid; u < H * Pq * 3; u += 256) sqp[u] = qp[(size_t)bi * H * Pq * 3 + u];
+    for (int u = tid; u < H * C; u += IPA_NT) sq[u] = q[(size_t)bi * H * C + u];
+    for (int u = tid; u < H * Pq * 3; u += IPA_NT) sqp[u] = qp[(size_t)bi * H * Pq * 3 + u];
     __syncthreads();
     const float mi = rmask[bi];
     const float cpt = sqrtf(1.0f / (3.0f * ((float)Pq * 9.0f / 2.0f)));
-    for (int u = tid; u < H * N; u += 256) {
+    for (int u = tid; u < H * N; u += IPA_NT) {
         const int h = u / N, j = u % N;
         const size_t mj = (size_t)b * N + j;
         const float* kr = kv + (mj * H + h) * 2 * C;
@@ -871,7 +877,7 @@ __global__ __launch_bounds__(256) void k_ipa_fwd(IpaDims d, const float* __restr
     __syncthreads();
     {   // softmax over j, one wave per head at a time
         const int wave = tid >> 6, lane = tid & 63;
-        for (int h = wave; h < H; h += 4) {
+        for (int h = wave; h < H; h += IPA_NT / 64) {
             float mx = -3.0e38f;
             for (int j = lane; j < N; j += 64) mx = fmaxf(mx, att[h * N + j]);
             for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
@@ -885,23 +891,23 @@ __global__ __launch_bounds__(256) void k_ipa_fwd(IpaDims d, const float* __restr
     __syncthreads();
     const int ncat = H * (C + 4 * Pv + cp);
     float* crow = cat + (size_t)bi * ncat;
-    for (int u = tid; u < H * C; u += 256) {          // o
+    for (int u = tid; u < H * C; u += IPA_NT) {          // o
         const int h = u / C, c = u % C;
         float s = 0.f;
 #pragma unroll 8
         for (int j = 0; j < N; ++j) s += att[h * N + j] * kv[(((size_t)b * N + j) * H + h) * 2 * C + C + c];
         crow[u] = s;
     }
-    for (int u = tid; u < H * Pv * 3; u += 256) {     // o_pt, global frame
+    for (int u = tid; u < H * Pv * 3; u += IPA_NT) {     // o_pt, global frame
         const int h = u / (Pv * 3), t = u % (Pv * 3);
         float s = 0.f;
 #pragma unroll 8
         for (int j = 0; j < N; ++j) s += att[h * N + j] * vp[(((size_t)b * N + j) * H + h) * Pv * 3 + t];
         sopt[u] = s;
     }
-    if (256 % cp == 0 && H <= 16) {                   // o_pair: a thread keeps its channel and walks every (256 / cp)-th j -- each pair
-        const int c = tid % cp, part = tid / cp, nparts = 256 / cp;       // row is read once, for all heads; the parts meet in LDS
-        float* spart = sopt + H * Pv * 3;             // [nparts][H][cp]
+    if (IPA_NT % cp == 0 && H <= 16) {                // o_pair: a thread keeps its channel and walks every (IPA_NT / cp)-th j -- each pair
+        const int c = tid % cp, part = tid / cp, nparts = IPA_NT / cp;    // row is read once, for all heads; the parts are then summed
+        float* sbuf = sopt + H * Pv * 3;              // pairwise through LDS ([nparts / 2][H][cp]; a fixed order: no float atomics)
         float acc[16];
 #pragma unroll
         for (int h = 0; h < 16; ++h) acc[h] = 0.f;
@@ -911,16 +917,24 @@ __global__ __launch_bounds__(256) void k_ipa_fwd(IpaDims d, const float* __restr
 #pragma unroll
             for (int h = 0; h < 16; ++h) if (h < H) acc[h] += att[h * N + j] * pv;
         }
+        for (int half = nparts >> 1; half >= 1; half >>= 1) {
+            if (part >= half && part < 2 * half) {
 #pragma unroll
-        for (int h = 0; h < 16; ++h) if (h < H) spart[(part * H + h) * cp + c] = acc[h];
-        __syncthreads();
-        for (int u = tid; u < H * cp; u += 256) {
-            float sacc = 0.f;
-            for (int q = 0; q < nparts; ++q) sacc += spart[q * H * cp + u];
-            crow[H * C + 4 * H * Pv + u] = sacc;
+                for (int h = 0; h < 16; ++h) if (h < H) sbuf[((part - half) * H + h) * cp + c] = acc[h];
+            }
+            __syncthreads();
+            if (part < half) {
+#pragma unroll
+                for (int h = 0; h < 16; ++h) if (h < H) acc[h] += sbuf[(part * H + h) * cp + c];
+            }
+            __syncthreads();
+        }
+        if (part == 0) {
+#pragma unroll
+            for (int h = 0; h < 16; ++h) if (h < H) crow[H * C + 4 * H * Pv + h * cp + c] = acc[h];
         }
     } else {
-        for (int u = tid; u < H * cp; u += 256) {
+        for (int u = tid; u < H * cp; u += IPA_NT) {
             const int h = u / cp, c = u % cp;
             float s = 0.f;
 #pragma unroll 8
@@ -931,7 +945,7 @@ __global__ __launch_bounds__(256) void k_ipa_fwd(IpaDims d, const float* __restr
     __syncthreads();
     const float* R = rots + (size_t)bi * 9;
     const float* T = trans + (size_t)bi * 3;
-    for (int u = tid; u < H * Pv; u += 256) {         // local frame: R^T (g - t), and its norm
+    for (int u = tid; u < H * Pv; u += IPA_NT) {         // local frame: R^T (g - t), and its norm
         const float w0 = sopt[u * 3] - T[0], w1 = sopt[u * 3 + 1] - T[1], w2 = sopt[u * 3 + 2] - T[2];
         const float l0 = R[0] * w0 + R[3] * w1 + R[6] * w2, l1 = R[1] * w0 + R[4] * w1 + R[7] * w2, l2 = R[2] * w0 + R[5] * w1 + R[8] * w2;
         crow[H * C + u] = l0; crow[H * C + H * Pv + u] = l1; crow[H * C + 2 * H * Pv + u] = l2;
@@ -941,7 +955,8 @@ __global__ __launch_bounds__(256) void k_ipa_fwd(IpaDims d, const float* __restr
 
 // backward, per query (b, i): d logits (kept for the per-key kernel and the linear_b gradient), dq, dq_pts (global), the pair
 // gradient rows (b, i, :, :), d head_weights, the query's own frame gradient from the output points
-__global__ __launch_bounds__(256) void k_ipa_bwd_q(IpaDims d, const float* __restrict__ q, const float* __restrict__ kv, const float* __restrict__ qp,
+template <int HT>      // head count at compile time (0: d.H) -- the per-head loops are unrolled over registers
+__global__ __launch_bounds__(IPA_NT) void k_ipa_bwd_q(IpaDims d, const float* __restrict__ q, const float* __restrict__ kv, const float* __restrict__ qp,
                                                    const float* __restrict__ kp, const float* __restrict__ vp, const float* __restrict__ p,
                                                    const float* __restrict__ rots, const float* __restrict__ trans, const float* __restrict__ head_w,
                                                    const float* __restrict__ wb, const float* __restrict__ att_in, const float* __restrict__ cat,
@@ -949,7 +964,7 @@ __global__ __launch_bounds__(256) void k_ipa_bwd_q(IpaDims d, const float* __res
                                                    float* __restrict__ doptg, float* __restrict__ dP, float* __restrict__ dhead, float* __restrict__ dbb,
                                                    float* __restrict__ dR, float* __restrict__ dT) {
     extern __shared__ float sm[];
-    const int N = d.N, H = d.H, C = d.C, Pq = d.Pq, Pv = d.Pv, cp = d.cp;
+    const int N = d.N, H = HT > 0 ? HT : d.H, C = d.C, Pq = d.Pq, Pv = d.Pv, cp = d.cp;
     float* att = sm;                        // [H][N]
     float* dat = att + H * N;               // [H][N] d att -> d logits
     float* sdo = dat + H * N;               // [H C]
@@ -964,12 +979,12 @@ __global__ __launch_bounds__(256) void k_ipa_bwd_q(IpaDims d, const float* __res
     const float* drow = dcat + (size_t)bi * ncat;
     const float* R = rots + (size_t)bi * 9;
     if (tid < 16) red[tid] = 0.f;
-    for (int u = tid; u < H * N; u += 256) { const int h = u / N, j = u % N; att[u] = att_in[(((size_t)b * H + h) * N + i) * N + j]; }
-    for (int u = tid; u < H * C; u += 256) { sdo[u] = drow[u]; sq[u] = q[(size_t)bi * H * C + u]; }
-    for (int u = tid; u < H * cp; u += 256) sdop[u] = drow[H * C + 4 * H * Pv + u];
-    for (int u = tid; u < H * Pq * 3; u += 256) sqp[u] = qp[(size_t)bi * H * Pq * 3 + u];
+    for (int u = tid; u < H * N; u += IPA_NT) { const int h = u / N, j = u % N; att[u] = att_in[(((size_t)b * H + h) * N + i) * N + j]; }
+    for (int u = tid; u < H * C; u += IPA_NT) { sdo[u] = drow[u]; sq[u] = q[(size_t)bi * H * C + u]; }
+    for (int u = tid; u < H * cp; u += IPA_NT) sdop[u] = drow[H * C + 4 * H * Pv + u];
+    for (int u = tid; u < H * Pq * 3; u += IPA_NT) sqp[u] = qp[(size_t)bi * H * Pq * 3 + u];
     __syncthreads();
-    for (int u = tid; u < H * Pv; u += 256) {         // through norm and local frame: l = R^T w, w = g - t
+    for (int u = tid; u < H * Pv; u += IPA_NT) {         // through norm and local frame: l = R^T w, w = g - t
         const float l0 = crow[H * C + u], l1 = crow[H * C + H * Pv + u], l2 = crow[H * C + 2 * H * Pv + u], nr = crow[H * C + 3 * H * Pv + u];
         const float dn = drow[H * C + 3 * H * Pv + u] / nr;
         const float g0 = drow[H * C + u] + dn * l0, g1 = drow[H * C + H * Pv + u] + dn * l1, g2 = drow[H * C + 2 * H * Pv + u] + dn * l2;
@@ -994,7 +1009,7 @@ __global__ __launch_bounds__(256) void k_ipa_bwd_q(IpaDims d, const float* __res
         const int jj = tid & 63, hg = tid >> 6;
         for (int j0 = 0; j0 < N; j0 += 64) {
 #pragma unroll 8
-            for (int u = tid; u < 64 * cp; u += 256) {
+            for (int u = tid; u < 64 * cp; u += IPA_NT) {
                 const int r = u / cp, c = u - r * cp;
                 pt[r * (cp + 1) + c] = j0 + r < N ? p[((size_t)bi * N + j0 + r) * cp + c] : 0.f;
             }
@@ -1006,12 +1021,12 @@ __global__ __launch_bounds__(256) void k_ipa_bwd_q(IpaDims d, const float* __res
                 for (int c = 0; c < cp; ++c) {
                     const float pv = prow[c];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) if (hg + 4 * t < H) acc[t] += sdop[(hg + 4 * t) * cp + c] * pv;
+                    for (int t = 0; t < 4; ++t) if (hg + (IPA_NT / 64) * t < H) acc[t] += sdop[(hg + (IPA_NT / 64) * t) * cp + c] * pv;
                 }
                 const size_t mj = (size_t)b * N + j;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const int h = hg + 4 * t;
+                    const int h = hg + (IPA_NT / 64) * t;
                     if (h >= H) continue;
                     float sacc = acc[t];
                     const float* vr = kv + (mj * H + h) * 2 * C + C;
@@ -1027,7 +1042,7 @@ __global__ __launch_bounds__(256) void k_ipa_bwd_q(IpaDims d, const float* __res
     const float cpt = sqrtf(1.0f / (3.0f * ((float)Pq * 9.0f / 2.0f)));
     if (!(d.skip & 2)) {   // d logits = att (d att - sum_j att d att); d head_weights, d bias of linear_b
         const int wave = tid >> 6, lane = tid & 63;
-        for (int h = wave; h < H; h += 4) {
+        for (int h = wave; h < H; h += IPA_NT / 64) {
             float s = 0.f;
             for (int j = lane; j < N; j += 64) s += att[h * N + j] * dat[h * N + j];
             for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -1051,14 +1066,14 @@ __global__ __launch_bounds__(256) void k_ipa_bwd_q(IpaDims d, const float* __res
         }
     }
     __syncthreads();
-    for (int u = tid; u < ((d.skip & 4) ? 0 : H * C); u += 256) {          // dq
+    for (int u = tid; u < ((d.skip & 4) ? 0 : H * C); u += IPA_NT) {          // dq
         const int h = u / C, c = u % C;
         float s = 0.f;
 #pragma unroll 8
         for (int j = 0; j < N; ++j) s += dat[h * N + j] * kv[(((size_t)b * N + j) * H + h) * 2 * C + c];
         dq[(size_t)bi * H * C + u] = s * d.c_qk;
     }
-    for (int u = tid; u < ((d.skip & 8) ? 0 : H * Pq * 3); u += 256) {     // dq_pts (global): -hw sum_j dlogit (qp - kp_j)
+    for (int u = tid; u < ((d.skip & 8) ? 0 : H * Pq * 3); u += IPA_NT) {     // dq_pts (global): -hw sum_j dlogit (qp - kp_j)
         const int h = u / (Pq * 3), t = u % (Pq * 3);
         float s = 0.f;
 #pragma unroll 8
@@ -1067,20 +1082,20 @@ __global__ __launch_bounds__(256) void k_ipa_bwd_q(IpaDims d, const float* __res
     }
     // pair gradient rows (b, i, j, :) += sum_h att do_pair + c_b dlogit W_b
     if (d.skip & 16) return;
-    if (256 % cp == 0 && H <= 16) {         // a thread keeps its channel: its column of d o_pair and W_b stays in registers
+    if (IPA_NT % cp == 0 && H <= 16) {         // a thread keeps its channel: its column of d o_pair and W_b stays in registers
         const int c = tid % cp;
         float so[16], sw[16];
 #pragma unroll
         for (int h = 0; h < 16; ++h) { so[h] = h < H ? sdop[h * cp + c] : 0.f; sw[h] = h < H ? d.c_b * wb[h * cp + c] : 0.f; }
 #pragma unroll 8
-        for (int j = tid / cp; j < N; j += 256 / cp) {
+        for (int j = tid / cp; j < N; j += IPA_NT / cp) {
             float sacc = 0.f;
 #pragma unroll
             for (int h = 0; h < 16; ++h) if (h < H) sacc += att[h * N + j] * so[h] + dat[h * N + j] * sw[h];
             dP[((size_t)bi * N + j) * cp + c] += sacc;
         }
     } else {
-        for (int c = tid; c < cp; c += 256) {
+        for (int c = tid; c < cp; c += IPA_NT) {
 #pragma unroll 8
             for (int j = 0; j < N; ++j) {
                 float sacc = 0.f;
@@ -1091,24 +1106,25 @@ __global__ __launch_bounds__(256) void k_ipa_bwd_q(IpaDims d, const float* __res
     }
 }
 // backward, per key (b, j): dk, dv (into dkv), dk_pts, dv_pts (global)
-__global__ __launch_bounds__(256) void k_ipa_bwd_k(IpaDims d, const float* __restrict__ q, const float* __restrict__ qp, const float* __restrict__ kp,
+template <int HT>      // head count at compile time (0: d.H) -- the per-head loops are unrolled over registers
+__global__ __launch_bounds__(IPA_NT) void k_ipa_bwd_k(IpaDims d, const float* __restrict__ q, const float* __restrict__ qp, const float* __restrict__ kp,
                                                    const float* __restrict__ head_w, const float* __restrict__ att_in, const float* __restrict__ dlg,
                                                    const float* __restrict__ dcat, const float* __restrict__ doptg, float* __restrict__ dkv,
                                                    float* __restrict__ dkp, float* __restrict__ dvp) {
     extern __shared__ float sm[];
-    const int N = d.N, H = d.H, C = d.C, Pq = d.Pq, Pv = d.Pv, cp = d.cp;
+    const int N = d.N, H = HT > 0 ? HT : d.H, C = d.C, Pq = d.Pq, Pv = d.Pv, cp = d.cp;
     float* att = sm;                // [H][N] over queries i
     float* dl = att + H * N;        // [H][N]
     const int bj = blockIdx.x, b = bj / N, j = bj % N, tid = threadIdx.x;
     const int ncat = H * (C + 4 * Pv + cp);
-    for (int u = tid; u < H * N; u += 256) {
+    for (int u = tid; u < H * N; u += IPA_NT) {
         const int h = u / N, i = u % N;
         att[u] = att_in[(((size_t)b * H + h) * N + i) * N + j];
         dl[u] = dlg[(((size_t)b * H + h) * N + i) * N + j];
     }
     __syncthreads();
     const float cpt = sqrtf(1.0f / (3.0f * ((float)Pq * 9.0f / 2.0f)));
-    for (int u = tid; u < H * C; u += 256) {
+    for (int u = tid; u < H * C; u += IPA_NT) {
         const int h = u / C, c = u % C;
         float sk = 0.f, sv = 0.f;
         for (int i = 0; i < N; ++i) {
@@ -1119,14 +1135,14 @@ __global__ __launch_bounds__(256) void k_ipa_bwd_k(IpaDims d, const float* __res
         dkv[((size_t)bj * H + h) * 2 * C + c] = sk * d.c_qk;
         dkv[((size_t)bj * H + h) * 2 * C + C + c] = sv;
     }
-    for (int u = tid; u < H * Pq * 3; u += 256) {
+    for (int u = tid; u < H * Pq * 3; u += IPA_NT) {
         const int h = u / (Pq * 3);
         float s = 0.f;
         const float kpv = kp[(size_t)bj * H * Pq * 3 + u];
         for (int i = 0; i < N; ++i) s += dl[h * N + i] * (qp[((size_t)b * N + i) * H * Pq * 3 + u] - kpv);
         dkp[(size_t)bj * H * Pq * 3 + u] = softplus_dev(head_w[h]) * cpt * s;
     }
-    for (int u = tid; u < H * Pv * 3; u += 256) {
+    for (int u = tid; u < H * Pv * 3; u += IPA_NT) {
         const int h = u / (Pv * 3);
         float s = 0.f;
         for (int i = 0; i < N; ++i) s += att[h * N + i] * doptg[((size_t)b * N + i) * H * Pv * 3 + u];
@@ -1137,24 +1153,34 @@ static int ipa_skip() { static const int v = getenv("GENIE_IPA_SKIP") ? atoi(get
 size_t ipa_train_lds(int N, int H, int C, int Pq, int Pv, int cp) {
     return (size_t)(2 * H * N + 2 * H * C + H * Pv * 3 + H * cp + H * Pq * 3 + 16) * sizeof(float);
 }
+template <int HT>
+static void launch_ipa_fwd_t(hipStream_t st, const IpaArgs& a, const IpaDims& d, size_t lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_fwd<HT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_ipa_fwd<HT>, dim3(a.B * a.N), dim3(IPA_NT), lds, st, d, a.q, a.kv, a.qp, a.kp, a.vp, a.bias, a.p, a.rots, a.trans, a.rmask,
+                       a.head_w, a.att, a.cat);
+}
 void launch_ipa_fwd(hipStream_t st, const IpaArgs& a) {
     IpaDims d{a.B, a.N, a.H, a.C, a.Pq, a.Pv, a.cp, sqrtf(1.0f / (3.0f * a.C)), sqrtf(1.0f / 3.0f), ipa_skip()};
-    // the forward kernel lays out att [H N], q, q points, output points, then the o_pair partial sums [256 / cp][H][cp]
-    const size_t lds = (size_t)(a.H * a.N + a.H * a.C + a.H * a.Pq * 3 + a.H * a.Pv * 3 + (a.cp <= 256 && 256 % a.cp == 0 ? (256 / a.cp) * a.H * a.cp : 0)) * sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_ipa_fwd, dim3(a.B * a.N), dim3(256), lds, st, d, a.q, a.kv, a.qp, a.kp, a.vp, a.bias, a.p, a.rots, a.trans, a.rmask,
-                       a.head_w, a.att, a.cat);
+    // the forward kernel lays out att [H N], q, q points, output points, then the o_pair exchange buffer [IPA_NT / cp / 2][H][cp]
+    const size_t lds = (size_t)(a.H * a.N + a.H * a.C + a.H * a.Pq * 3 + a.H * a.Pv * 3 + (IPA_NT % a.cp == 0 ? (IPA_NT / a.cp / 2) * a.H * a.cp : 0)) * sizeof(float);
+    if (a.H == 12) launch_ipa_fwd_t<12>(st, a, d, lds);     // the released models' head count
+    else launch_ipa_fwd_t<0>(st, a, d, lds);
+}
+template <int HT>
+static void launch_ipa_bwd_t(hipStream_t st, const IpaArgs& a, const IpaDims& d, size_t lds, size_t lds_q) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_bwd_q<HT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_bwd_k<HT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_ipa_bwd_q<HT>, dim3(a.B * a.N), dim3(IPA_NT), lds_q, st, d, a.q, a.kv, a.qp, a.kp, a.vp, a.p, a.rots, a.trans, a.head_w, a.wb,
+                       a.att, a.cat, a.dcat, a.dlg, a.dq, a.dqp, a.doptg, a.dP, a.dhead, a.dbb, a.dR, a.dT);
+    hipLaunchKernelGGL(k_ipa_bwd_k<HT>, dim3(a.B * a.N), dim3(IPA_NT), lds, st, d, a.q, a.qp, a.kp, a.head_w, a.att, a.dlg, a.dcat, a.doptg, a.dkv,
+                       a.dkp, a.dvp);
 }
 void launch_ipa_bwd(hipStream_t st, const IpaArgs& a) {
     IpaDims d{a.B, a.N, a.H, a.C, a.Pq, a.Pv, a.cp, sqrtf(1.0f / (3.0f * a.C)), sqrtf(1.0f / 3.0f), ipa_skip()};
     const size_t lds = ipa_train_lds(a.N, a.H, a.C, a.Pq, a.Pv, a.cp);
     const size_t lds_q = lds + (size_t)64 * (a.cp + 1) * sizeof(float);            // + the staged tile of pair rows
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_bwd_q), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_bwd_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_ipa_bwd_q, dim3(a.B * a.N), dim3(256), lds_q, st, d, a.q, a.kv, a.qp, a.kp, a.vp, a.p, a.rots, a.trans, a.head_w, a.wb,
-                       a.att, a.cat, a.dcat, a.dlg, a.dq, a.dqp, a.doptg, a.dP, a.dhead, a.dbb, a.dR, a.dT);
-    hipLaunchKernelGGL(k_ipa_bwd_k, dim3(a.B * a.N), dim3(256), lds, st, d, a.q, a.qp, a.kp, a.head_w, a.att, a.dlg, a.dcat, a.doptg, a.dkv,
-                       a.dkp, a.dvp);
+    if (a.H == 12) launch_ipa_bwd_t<12>(st, a, d, lds, lds_q);
+    else launch_ipa_bwd_t<0>(st, a, d, lds, lds_q);
 }
 
 // ------------------------------------------------------------------------------------------------ points and frames

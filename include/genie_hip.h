@@ -240,7 +240,7 @@ int genie_denoise_vjp(genie_handle_t h, genie_stream_t stream, const float* weig
 size_t genie_train_workspace_bytes(genie_handle_t h);
 
 /* The training path's building block, exposed so that it can be checked on its own (tests/test_train_gemm.py; the reference has no
- * counterpart: there these are torch.nn.Linear / einsum calls inside autograd, genie/model/*.py).  Device pointers, element strides:
+ * counterpart: there these are torch.nn.Linear / einsum calls inside autograd, the files under genie/model).  Device pointers, element strides:
  *   C[z][m][n] (op)= alpha * sum_k A[z][m][k] B[z][k][n] (+ bias[n]),   z = z1 * nb2 + z2,  z1 < batch / nb2
  *   A at a + z1 a1 + z2 a2 + m am + k ak;  B at b + z1 b1 + z2 b2 + k bk + n bn;  C at c + z1 c1 + z2 c2 + m cm + n cn
  * mode 0 store (then optionally relu, and / or zero where gate <= 0, gate laid out like C), 1 add, 2 atomic add (required for

@@ -120,6 +120,27 @@ def test_gradients_match_oracle_autograd_base_model_n128():
     eng.close()
 
 
+def test_gradients_match_oracle_autograd_other_head_count():
+    """five IPA heads: the IPA training kernels are compiled for the released models' twelve and fall back to a run-time head count
+    otherwise -- this is the only case that takes the fallback"""
+    from genie2_amd.engine import GenieEngine
+    dims = O.small_dims(n_head_ipa=5)
+    sd = O.synthetic_state_dict(dims, seed=9)
+    f, z, g = _case(21, [19, 24])
+    sched = O.training_schedule(dims['n_timestep'])
+    s = torch.tensor([60, 8])
+    fr = O.prepare_features(f)
+    trans, rots = O.q_sample(f['atom_positions'], s, z, fr['chain_index'], fr['residue_mask'], sched)
+    zo, lo, gref = _oracle_grads(sd, dims, rots, trans, s.int(), f, z, 1.0)
+    eng = GenieEngine(dims, sd, 'cuda:0')
+    eng.bind_features(f)
+    out = eng.train_forward_backward(flat(sd, dims).cuda(), trans, rots, s.int(), z, 1.0, train_mode=False)
+    m = fr['residue_mask'].unsqueeze(-1).float()
+    assert float(((out['z'].cpu() - zo) * m).abs().max()) <= 2e-4 * max(1.0, float(zo.abs().max()))
+    check_grads(split(out['grads'].cpu(), dims), gref)
+    eng.close()
+
+
 @pytest.mark.parametrize('rescale', [1.0, 2.0])
 def test_gradients_match_oracle_autograd_small_dims(rescale):
     """ragged batch, motif conditioning, two chains, odd shapes: every gradient against torch autograd over the oracle"""
