@@ -866,10 +866,12 @@ __global__ __launch_bounds__(IPA_NT) void k_ipa_fwd(IpaDims d, const float* __re
         const size_t mj = (size_t)b * N + j;
         const float* kr = kv + (mj * H + h) * 2 * C;
         float a = 0.f;
+#pragma unroll 8
         for (int c = 0; c < C; ++c) a += sq[h * C + c] * kr[c];
         a = a * d.c_qk + d.c_b * bias[((size_t)bi * N + j) * H + h];
         float ds = 0.f;
         const float* kpr = kp + (mj * H + h) * Pq * 3;
+#pragma unroll 4
         for (int t = 0; t < Pq * 3; ++t) { const float df = sqp[h * Pq * 3 + t] - kpr[t]; ds += df * df; }
         a += -0.5f * softplus_dev(head_w[h]) * cpt * ds + 1e5f * (mi * rmask[mj] - 1.0f);
         att[u] = a;
@@ -1018,6 +1020,7 @@ __global__ __launch_bounds__(IPA_NT) void k_ipa_bwd_q(IpaDims d, const float* __
             if (j < N) {
                 float acc[4] = {0.f, 0.f, 0.f, 0.f};
                 const float* prow = pt + jj * (cp + 1);
+#pragma unroll 8
                 for (int c = 0; c < cp; ++c) {
                     const float pv = prow[c];
 #pragma unroll
@@ -1030,8 +1033,10 @@ __global__ __launch_bounds__(IPA_NT) void k_ipa_bwd_q(IpaDims d, const float* __
                     if (h >= H) continue;
                     float sacc = acc[t];
                     const float* vr = kv + (mj * H + h) * 2 * C + C;
+#pragma unroll 8
                     for (int c = 0; c < C; ++c) sacc += sdo[h * C + c] * vr[c];
                     const float* vpr = vp + (mj * H + h) * Pv * 3;
+#pragma unroll 4
                     for (int q3 = 0; q3 < Pv * 3; ++q3) sacc += sdg[h * Pv * 3 + q3] * vpr[q3];
                     dat[h * N + j] = sacc;
                 }
@@ -1054,6 +1059,7 @@ __global__ __launch_bounds__(IPA_NT) void k_ipa_bwd_q(IpaDims d, const float* __
                 sb += g;
                 float ds = 0.f;
                 const float* kpr = kp + (((size_t)b * N + j) * H + h) * Pq * 3;
+#pragma unroll 4
                 for (int t = 0; t < Pq * 3; ++t) { const float df = sqp[h * Pq * 3 + t] - kpr[t]; ds += df * df; }
                 sh += g * ds;
             }
