@@ -36,12 +36,10 @@ def durations(sub):
 
 fetch, write = counters('pass_fetch', 'FETCH_SIZE'), counters('pass_write', 'WRITE_SIZE')
 dur = durations('stats')
-h = hashlib.sha256()
-d = os.path.join(ROOT, 'genie2_amd', 'csrc')
-for n in sorted(os.listdir(d)):
-    h.update(open(os.path.join(d, n), 'rb').read())
+sys.path.insert(0, ROOT)
+from bench import kernels_sha  # noqa: E402  (one definition of "the sources these numbers belong to")
 blob = {'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --steps 4 --warmup 2; FETCH_SIZE doubled (gfx950)',
-        'kernels_sha': h.hexdigest()[:16], 'hx': {}}
+        'kernels_sha': kernels_sha(), 'hx': {}}
 for k in sorted(set(fetch) | set(write)):
     if not k.startswith('k_'):
         continue
