@@ -31,7 +31,10 @@ int main(int argc, char** argv) {
         {"dW   dY[R,128]^T X[R,128] auto  ", 128, 128, (int)R, 1, 128, 128, 1, 128, 1, -1, 2},
         {"dW   dY[R,128]^T X[R,128] s=48  ", 128, 128, (int)R, 1, 128, 128, 1, 128, 1, 48, 2},
         {"dW   dY[R,128]^T X[R,128] s=96  ", 128, 128, (int)R, 1, 128, 128, 1, 128, 1, 96, 2},
+        {"dW   dY[R,128]^T X[R,128] s=256 ", 128, 128, (int)R, 1, 128, 128, 1, 128, 1, 256, 2},      // >= 256 tiles of 128: the big kernel
+        {"dW   dY[R,128]^T X[R,128] s=512 ", 128, 128, (int)R, 1, 128, 128, 1, 128, 1, 512, 2},
         {"dW   dY[R,512]^T X[R,128] auto  ", 512, 128, (int)R, 1, 512, 128, 1, 128, 1, -1, 2},
+        {"dW   dY[R,512]^T X[R,128] s=128 ", 512, 128, (int)R, 1, 512, 128, 1, 128, 1, 128, 2},
         {"s    X[256,384] W[384,384]^T    ", 256, 384, 384, 384, 1, 1, 384, 384, 1, 1, 0},
         {"s    X[256,2112] W[384,2112]^T  ", 256, 384, 2112, 2112, 1, 1, 2112, 384, 1, 1, 0},
     };
