@@ -22,7 +22,8 @@ WRITE_SIZE passes (profiles/), null if that kernel was not profiled.
 host: 1 warm-up + 3 timed consecutive steps of the same workload, median.
 At N=1 the same line also carries `value_f32` (the same K steps in the exact-f32
 MFMA kernels), `hx_vs_f32` (distance of the two trajectories after those steps)
-and `full_loop` (all T=1000 reverse steps of one batch, timed end to end).
+and `full_loop` (all T=1000 reverse steps of one batch, timed end to end), and `train_step` (BASELINE config 5's shape on one
+GPU: forward + backward + Adam of the base model at N=256, batch 2, f32-grade arithmetic, 1 warm-up + 5 timed steps).
 """
 import argparse
 import json
@@ -176,6 +177,62 @@ def cpu_baseline(dims, B, N, seed, n_timed=3):
                       f'batch={B}, fp32, oracle/genie_oracle.py with torch.linalg.eigh quaternions; median {med:.1f} s per step'}
 
 
+def train_step_leg(eng, dims, dev, N=256, B=2, n_timed=5):
+    """BASELINE config 5's shape on one GPU: one training step (genie_train_forward_backward: train-mode forward, loss, backward
+    through the whole Denoiser; then genie_adam_step) of the base model on a synthetic batch, f32-grade arithmetic (fast_math 0:
+    every f32 operand as three bf16 pieces, six MFMAs per product -- the reference trains in fp32, train.py:54-65).  1 warm-up +
+    `n_timed` timed steps; then one more step with per-class HIP events for the roofline of the dominant class."""
+    from genie2_amd.engine import adam_step
+    sd = pack.random_state_dict(dims, seed=0)
+    feats = F.convert_np_features_to_tensor(F.batchify_np_features([F.create_empty_np_features([N]) for _ in range(B)]), dev)
+    eng.bind_features(feats)
+    w = pack.flatten_state_dict(sd, dims).to(dev)
+    g, m, v = torch.zeros_like(w), torch.zeros_like(w), torch.zeros_like(w)
+    gen = torch.Generator().manual_seed(7)
+    x0 = (torch.randn(B, N, 3, generator=gen) * 8).to(dev)
+    z = torch.randn(B, N, 3, generator=gen).to(dev)
+    s = torch.randint(1, dims['n_timestep'] + 1, (B,), generator=gen).int().to(dev)
+    sched = pack.schedule_tensors(dims['n_timestep'])
+    trans, rots = eng.q_sample(x0, z, sched['sqrt_alphas_cumprod'].to(dev)[s.long()], sched['sqrt_one_minus_alphas_cumprod'].to(dev)[s.long()])
+
+    def one(it):
+        out = eng.train_forward_backward(w, trans, rots, s, z, 1.0, grads=g, seed=it, fast_math=0)
+        adam_step(w, g, m, v, 1e-4, it + 1)
+        return out
+
+    one(0)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for it in range(n_timed):
+        out = one(1 + it)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / n_timed
+    loss = float(out['weighted_loss'])
+    eng.profile(True)
+    one(1 + n_timed)
+    torch.cuda.synchronize(dev)
+    eng.profile(False)
+    prof = {k: v for k, v in eng.profile_read().items() if k.startswith('train_') and v[1]}
+    flop = float(eng.lib.genie_train_gemm_flop(eng._h))
+    kern = {k: {'ms_per_step': round(ms, 3), 'launches_per_step': cnt} for k, (ms, cnt) in prof.items()}
+    dom = max(prof, key=lambda k: prof[k][0])
+    res = {'ms_per_step': dt * 1e3, 'steps': n_timed, 'warmup': 1, 'loss_finite': loss == loss and abs(loss) != float('inf'),
+           'config': {'workload': f'training step, base Denoiser (15.7M params), synthetic batch: N={N}, batch={B}, train-mode dropout, '
+                                  'forward + backward + Adam', 'arithmetic': 'fast_math 0: f32 operands as 3 bf16 pieces, 6 MFMAs per product, f32 accumulate'},
+           'gemm_algorithmic_tflop_per_step': flop / 1e12, 'algorithmic_tflops': flop / dt / 1e12,
+           'workspace_gib': eng.lib.genie_train_workspace_bytes(eng._h) / 2 ** 30, 'kept_gib': eng.lib.genie_train_kept_bytes(eng._h) / 2 ** 30,
+           'kernels': kern}
+    if dom == 'train_gemm':
+        ach = 6.0 * flop / (prof[dom][0] * 1e-3) / 1e12
+        res['roofline'] = {'bound': 'mfma', 'kernel': 'train_gemm (all GEMMs of the step)', 'achieved': ach, 'peak': PEAK_F16_MFMA_TFLOPS,
+                           'unit': 'TFLOP/s', 'frac': ach / PEAK_F16_MFMA_TFLOPS, 'traffic': None,
+                           'matrix_flop_per_step': 6.0 * flop, 'algorithmic_flop_per_step': flop, 'class_ms_per_step': prof[dom][0]}
+    else:
+        res['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': None, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': None, 'traffic': None,
+                           'class_ms_per_step': prof[dom][0]}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -185,6 +242,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra-legs', action='store_true', help='skip the other-arithmetic and full T=1000 legs (N=1 only)')
+    ap.add_argument('--no-train-leg', action='store_true', help='skip the training-step leg (N=1 only)')
     ap.add_argument('--profile-steps', type=int, default=3)
     ap.add_argument('--math', choices=['hx', 'f32'], default=None, help='pair-stack arithmetic (default: library default, hx)')
     args = ap.parse_args()
@@ -238,11 +296,10 @@ def main():
 
     dt, tr, ro = timed_leg()
     if dist:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        td.all_reduce(tmax, op=td.ReduceOp.MAX)
-        dt = float(tmax.item())
-        gathered = [torch.empty_like(tr) for _ in range(world)]      # trivial result gather over xGMI
-        td.all_gather(gathered, tr)
+        from genie2_amd.distributed import gather_coordinates, max_over_ranks
+        dt = max_over_ranks(dt, dev)
+        gathered = gather_coordinates(tr)                            # trivial result gather over xGMI: [world * B, N, 3]
+        assert gathered.shape[0] == world * B
     finite = bool(torch.isfinite(tr).all().item())
 
     out = None
@@ -327,6 +384,8 @@ def main():
             dtf = time.perf_counter() - t0
             out['full_loop'] = {'steps': T, 'seconds': dtf, 'batch_steps_per_s': T / dtf, 'structure_steps_per_s': T * B / dtf,
                                 'finite': bool(torch.isfinite(trf).all().item()), 'math': math}
+        if world == 1 and not args.no_extra_legs and not args.no_train_leg:
+            out['train_step'] = train_step_leg(eng, dims, dev)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(dims, B, N, 42)
             out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']

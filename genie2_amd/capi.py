@@ -75,6 +75,8 @@ SYMBOLS = {
                                                 C.c_void_p, C.c_float, C.POINTER(GenieTrainOpts), C.c_void_p, C.c_void_p]),
     'genie_denoise_vjp': (C.c_int, [C.c_void_p] * 10),
     'genie_train_workspace_bytes': (C.c_size_t, [C.c_void_p]),
+    'genie_train_kept_bytes': (C.c_size_t, [C.c_void_p]),
+    'genie_train_gemm_flop': (C.c_double, [C.c_void_p]),
     'genie_train_gemm': (C.c_int, [C.c_void_p, C.POINTER(GenieGemmDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'genie_p_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p]),

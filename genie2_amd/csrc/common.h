@@ -173,7 +173,8 @@ __device__ __forceinline__ void rot_to_quat_dev(const float* r, int code, float*
 enum KernelClass {
     KC_SINGLE_INPUT = 0, KC_GEMM_ROWS, KC_LAYERNORM, KC_PAIR_STATIC, KC_PAIR_INIT,
     KC_TRIMUL_PROJ, KC_TRIMUL_CONTRACT, KC_TRIMUL_OUT, KC_PAIR_TRANSITION,
-    KC_IPA_BIAS, KC_IPA_PREP, KC_IPA_ATTN, KC_BB_UPDATE, KC_STRUCT_ROWS, KC_P_SAMPLE, KC_MISC, KC_PAIR_FUSED_A, KC_PAIR_FUSED_B, KC_COUNT
+    KC_IPA_BIAS, KC_IPA_PREP, KC_IPA_ATTN, KC_BB_UPDATE, KC_STRUCT_ROWS, KC_P_SAMPLE, KC_MISC, KC_PAIR_FUSED_A, KC_PAIR_FUSED_B,
+    KC_TR_GEMM, KC_TR_EW, KC_TR_LN, KC_TR_TRANSPOSE, KC_TR_IPA, KC_TR_MISC, KC_COUNT      // training path (genie_train.hip)
 };
 
 // "hx" images (hx.h): weights split in f16 halves, in stage order, + the scales that go with them
@@ -266,6 +267,7 @@ struct genie_ctx {
     struct ProfRec { int cls; hipEvent_t a, b; };
     ProfRec* prof_recs; int prof_n, prof_cap;
     double prof_ms[KC_COUNT]; int64_t prof_cnt[KC_COUNT];
+    double train_gemm_flop;       // algorithmic FLOP (2 M N K per product) of the GEMMs the last training call launched
 };
 
 // launchers (each enqueues on `st`, no sync)

@@ -27,7 +27,7 @@ static char g_create_err[512] = "";
 static const char* kKernelNames[KC_COUNT] = {
     "single_input", "gemm_rows", "layernorm_rows", "pair_static", "pair_init", "trimul_proj", "trimul_contract",
     "trimul_out", "pair_transition", "ipa_bias", "ipa_prep", "ipa_attn", "bb_update", "struct_rows", "p_sample_frenet", "misc",
-    "pair_fused_a", "pair_fused_b"};
+    "pair_fused_a", "pair_fused_b", "train_gemm", "train_elementwise", "train_layernorm", "train_transpose", "train_ipa", "train_misc"};
 
 // ------------------------------------------------------------------ profiling
 void prof_begin(genie_ctx* h, hipStream_t st, int cls) {

@@ -106,7 +106,12 @@ struct Run {
     // ---- GEMM shapes -------------------------------------------------------------------------------------------------------
     void gemm(const GemmP& p) {
         if (dry) return;
-        static const bool log = getenv("GENIE_TRAIN_GEMM_LOG") != nullptr;      // developer aid: one line per GEMM with its own duration
+        h->train_gemm_flop += 2.0 * p.M * p.N * (double)p.K * p.batch;
+        ProfScope ps_(h, st, KC_TR_GEMM);
+#ifndef GENIE_DEV
+        launch_gemm(st, p, terms);
+#else
+        static const bool log = getenv("GENIE_TRAIN_GEMM_LOG") != nullptr;      // developer aid (-DGENIE_DEV builds): one line per GEMM with its own duration; synchronises
         if (!log) { launch_gemm(st, p, terms); return; }
         hipEvent_t e0, e1;
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -119,6 +124,7 @@ struct Run {
         fprintf(stderr, "GEMM M %d N %d K %d batch %d nsplit %d ak %lld bk %lld cn %lld mode %d us %.1f\n", p.M, p.N, p.K, p.batch, p.nsplit, p.ak, p.bk,
                 p.cn, p.mode, ms * 1e3f);
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+#endif
     }
     // Y[R][O] = X[R][K] (ld ldx) W[O][K]^T + b
     void lin_fwd(const float* X, long long ldx, long long R, int K, size_t w, long long b_off, int O, float* Y, int mode = 0, bool relu = false) {
@@ -141,14 +147,18 @@ struct Run {
         gemm(p);
     }
     void ln_fwd(const float* x, size_t g, size_t b, float* y, float* xhat, float* rstd, long long R, int C) {
-        if (!dry) launch_ln_fwd(st, x, W + g, W + b, y, xhat, rstd, R, C);
+        if (dry) return;
+        ProfScope ps_(h, st, KC_TR_LN);
+        launch_ln_fwd(st, x, W + g, W + b, y, xhat, rstd, R, C);
     }
     // dx (+)= LN backward; gamma / beta gradients
     void ln_bwd(const float* dy, const float* xhat, const float* rstd, size_t g, size_t b, float* dx, long long R, int C, bool accumulate) {
         if (dry) return;
+        ProfScope ps_(h, st, KC_TR_LN);
         launch_ln_bwd(st, dy, xhat, rstd, W + g, dx, R, C, accumulate ? 1 : 0, G ? G + g : nullptr, G ? G + b : nullptr);
     }
-    template <class F> void ew(long long n, F f) { if (!dry) launch_ew(st, n, f); }
+    template <class F> void ew(long long n, F f) { if (dry) return; ProfScope ps_(h, st, KC_TR_EW); launch_ew(st, n, f); }
+    void transpose(const float* in, float* out, int Bt, int R, int C, bool to_cm) { if (dry) return; ProfScope ps_(h, st, KC_TR_TRANSPOSE); launch_transpose(st, in, out, Bt, R, C, to_cm); }
 };
 }  // namespace
 
@@ -227,7 +237,7 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
                 brm[e] = bp[e] * m / (1.0f + expf(-bg[e]));
             });
         }
-        if (!dry) { launch_transpose(st, arm, s.acm, B, N * N, ch, true); launch_transpose(st, brm, s.bcm, B, N * N, ch, true); }
+        r.transpose(arm, s.acm, B, N * N, ch, true); r.transpose(brm, s.bcm, B, N * N, ch, true);
         float* xcm = arm;       // reuse
         {
             GemmP g{s.acm, s.bcm, xcm, nullptr, N, N, N, 0, 0, 0, 0, N, 1, B * ch, ch, (long long)ch * N * N, (long long)N * N,
@@ -237,7 +247,7 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
             r.gemm(g);
         }
         float* xrm = brm;
-        if (!dry) launch_transpose(st, xcm, xrm, B, N * N, ch, false);
+        r.transpose(xcm, xrm, B, N * N, ch, false);
         float* xn = arm;
         r.ln_fwd(xrm, t.lno_g, t.lno_b, xn, s.xhat_o, s.rstd_o, P, ch);
         r.lin_fwd(xn, ch, P, ch, t.z_w, t.z_b, cp, s.u);
@@ -301,7 +311,7 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
             a.B = B; a.N = N; a.H = H; a.C = C; a.Pq = Pq; a.Pv = Pv; a.cp = cp;
             a.q = v.q; a.kv = v.kv; a.qp = v.qp; a.kp = v.kp; a.vp = v.vp; a.bias = bias; a.p = z; a.rots = Rc; a.trans = Tc; a.rmask = rm;
             a.head_w = Wd + o.head; a.att = v.att; a.cat = v.cat;
-            if (!dry) launch_ipa_fwd(st, a);
+            if (!dry) { ProfScope ps_(h, st, KC_TR_IPA); launch_ipa_fwd(st, a); }
             float* s1 = T.f((size_t)M * cs);
             r.lin_fwd(v.cat, ncat, M, ncat, o.o_w, o.o_b, cs, s1);
             {
@@ -398,7 +408,7 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         a.head_w = Wd + o.head; a.wb = Wd + o.b_w; a.att = v.att; a.cat = v.cat; a.dcat = dcat;
         a.dlg = dlg; a.dq = dq; a.dqp = dqp; a.doptg = doptg; a.dP = dP; a.dhead = Gd ? Gd + o.head : gsink; a.dbb = Gd ? Gd + o.b_b : gsink + 32; a.dR = dRl; a.dT = dTl;
         a.dkv = dkv; a.dkp = dkp; a.dvp = dvp;
-        if (!dry) launch_ipa_bwd(st, a);
+        if (!dry) { ProfScope ps_(h, st, KC_TR_IPA); launch_ipa_bwd(st, a); }
         {   // linear_b weight: dWb[h][c] += c_b sum_{b,i,j} dlogit[b,h,i,j] p[b,i,j,c]
             GemmP g{dlg, z, Gd ? Gd + o.b_w : nullptr, nullptr, H, cp, N * N, (long long)N * N, 1, cp, 1, cp, 1, B, 1, (long long)H * N * N, 0, (long long)N * N * cp, 0, 0, 0,
                     gemm_splits(H, cp, (long long)N * N, B), sqrtf(1.0f / 3.0f), 2};
@@ -442,7 +452,7 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         float* dxrm = xn;
         r.ln_bwd(dxn, sv.xhat_o, sv.rstd_o, t.lno_g, t.lno_b, dxrm, P, ch, false);
         float* dxcm = dxn;
-        if (!dry) launch_transpose(st, dxrm, dxcm, B, N * N, ch, true);
+        r.transpose(dxrm, dxcm, B, N * N, ch, true);
         float* dacm = T.f(P * ch); float* dbcm = T.f(P * ch);
         {
             const long long bs1 = (long long)ch * N * N, bs2 = (long long)N * N;
@@ -458,7 +468,7 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
             r.gemm(ga); r.gemm(gb);
         }
         float* darm = xn; float* dbrm = dxn;
-        if (!dry) { launch_transpose(st, dacm, darm, B, N * N, ch, false); launch_transpose(st, dbcm, dbrm, B, N * N, ch, false); }
+        r.transpose(dacm, darm, B, N * N, ch, false); r.transpose(dbcm, dbrm, B, N * N, ch, false);
         float* dap = dacm; float* dag = dbcm; float* dbp = darm; float* dbg = dbrm;      // in place where the shapes allow
         {
             const float *ap = sv.ap, *ag = sv.ag, *bp = sv.bp, *bg = sv.bg;
@@ -555,6 +565,7 @@ int genie_train_forward_backward(genie_handle_t h, genie_stream_t stream, const 
     size_t kb = 0, tb = 0;
     train_run(h, st, true, weights, grads, trans, rots, timesteps, z_target, quat_codes, condition_loss_weight, *opts, losses_out, z_pred_out, &kb, &tb);
     if (int rc0 = train_alloc(h, st, kb, tb)) return rc0;
+    h->train_gemm_flop = 0.0;
     const int rc = train_run(h, st, false, weights, grads, trans, rots, timesteps, z_target, quat_codes, condition_loss_weight, *opts, losses_out,
                              z_pred_out, nullptr, nullptr);
     if (rc) return rc;
@@ -596,6 +607,8 @@ int genie_denoise_vjp(genie_handle_t h, genie_stream_t stream, const float* weig
 }
 
 size_t genie_train_workspace_bytes(genie_handle_t h) { return h && h->train ? h->train->kept_bytes + h->train->tmp_bytes : 0; }
+size_t genie_train_kept_bytes(genie_handle_t h) { return h && h->train ? h->train->kept_bytes : 0; }
+double genie_train_gemm_flop(genie_handle_t h) { return h ? h->train_gemm_flop : 0.0; }
 
 int genie_train_gemm(genie_stream_t stream, const genie_gemm_desc_t* q, const float* a, const float* b, float* c, const float* bias,
                      const float* gate, float* asum) {

@@ -574,7 +574,7 @@ void launch_pair_fused(genie_ctx* h, hipStream_t st, const HxFusedW& f, const Hx
     a.c1 = t ? t->c1 : 0.f; a.c2 = t ? t->c2 : 1.f; a.inv_c2 = t ? 1.0f / t->c2 : 1.f;
     a.cpa = p.cpa; a.cpb = p.cpb; a.cg = p.cg;
     a.rev = (int)(h->hx_launches++ & 1);
-    { const char* e = getenv("GENIE_FZ_STAGGER"); a.stagger = e ? atoi(e) : 0; }
+    { static const int stagger = [] { const char* e = getenv("GENIE_FZ_STAGGER"); return e ? atoi(e) : 0; }(); a.stagger = stagger; }      // developer knob, read once
     const long long n_tiles = ((long long)a.n_wtiles + 7) / 8;
     const unsigned grid = (unsigned)(n_tiles < fz_num_cu() ? n_tiles : fz_num_cu());
     if (!pp) hipLaunchKernelGGL((k_pair_fused<false, true, false>), dim3(grid), dim3(512), FZ_LDS_BYTES, st, a);

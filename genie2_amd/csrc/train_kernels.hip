@@ -1155,7 +1155,12 @@ __global__ __launch_bounds__(IPA_NT) void k_ipa_bwd_k(IpaDims d, const float* __
         dvp[(size_t)bj * H * Pv * 3 + u] = s;
     }
 }
+// developer knock-out of sections of the IPA kernels (wrong gradients by design): only in -DGENIE_DEV builds (GENIE_EXTRA_FLAGS)
+#ifdef GENIE_DEV
 static int ipa_skip() { static const int v = getenv("GENIE_IPA_SKIP") ? atoi(getenv("GENIE_IPA_SKIP")) : 0; return v; }
+#else
+static int ipa_skip() { return 0; }
+#endif
 size_t ipa_train_lds(int N, int H, int C, int Pq, int Pv, int cp) {
     return (size_t)(2 * H * N + 2 * H * C + H * Pv * 3 + H * cp + H * Pq * 3 + 16) * sizeof(float);
 }

@@ -38,6 +38,8 @@ class Genie(nn.Module):
         sd = ck['state_dict'] if 'state_dict' in ck else ck
         obj = cls(config)
         obj.model.load_state_dict({k[len('model.'):] if k.startswith('model.') else k: v for k, v in sd.items()})
+        # what a training run continues from (GenieTrainer.resume): Lightning keeps these next to the weights (train.py:35-39)
+        obj.checkpoint_info = {k: ck[k] for k in ('epoch', 'global_step', 'optimizer_states') if isinstance(ck, dict) and k in ck}
         return obj
 
 
@@ -102,13 +104,20 @@ def load_model(rootdir, name, version=None, epoch=None):
     return Genie.load_from_checkpoint(ckpt, config=load_config(rootdir, name))
 
 
-def save_checkpoint(genie, ckpt_filepath, epoch=0, global_step=0):
-    """Write the weights in the layout the reference's Lightning `Genie.load_from_checkpoint(path, config=...)` reads
-    (`state_dict` with `model.`-prefixed Denoiser keys, train.py:35-39): tensors only, loadable with weights_only=True."""
+def save_checkpoint(genie, ckpt_filepath, epoch=0, global_step=0, trainer=None):
+    """Write a checkpoint in the layout the reference's Lightning `Genie.load_from_checkpoint(path, config=...)` reads and its
+    `ModelCheckpoint(filename='{epoch}', save_top_k=-1)` writes (train.py:35-39): `state_dict` with `model.`-prefixed Denoiser keys,
+    `optimizer_states` = [torch.optim.Adam.state_dict()] over the parameters in that order, `epoch`, `global_step`.  Containers,
+    numbers and tensors only: loadable with weights_only=True.  With `trainer` (a GenieTrainer) the weights and the Adam moments
+    come from its device blobs and the live module / engine are left alone; without, weights only (from `genie`)."""
     os.makedirs(os.path.dirname(os.path.abspath(ckpt_filepath)), exist_ok=True)
-    sd = {'model.' + k: v.detach().cpu() for k, v in genie.model.state_dict().items()}
-    torch.save({'epoch': int(epoch), 'global_step': int(global_step), 'pytorch-lightning_version': 'none',
-                'state_dict': sd}, ckpt_filepath)
+    src = trainer.state_dict() if trainer is not None else genie.model.state_dict()
+    ck = {'epoch': int(epoch), 'global_step': int(global_step), 'pytorch-lightning_version': 'none',
+          'state_dict': {'model.' + k: v.detach().cpu() for k, v in src.items()}}
+    if trainer is not None:
+        ck['optimizer_states'] = [trainer.optimizer_state_dict()]
+        ck['lr_schedulers'] = []
+    torch.save(ck, ckpt_filepath)
 
 
 def mse(x_pred, x, mask, aggregate=None, eps=1e-10):

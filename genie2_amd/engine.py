@@ -162,6 +162,8 @@ class GenieEngine:
         tr, ro = self._dev(trans, torch.float32), self._dev(rots, torch.float32)
         ts, zt = self._dev(timesteps, torch.int32), self._dev(z_target, torch.float32)
         codes = self._dev(quat_codes, torch.int8) if quat_codes is not None else None
+        if struct_done_event is not None and not struct_done_event.cuda_event:
+            raise capi.GenieError('struct_done_event has no hipEvent behind it yet (torch creates it at the first record()): record it once')
         opts = capi.GenieTrainOpts(float(tri_dropout), float(ipa_dropout), float(transition_dropout), int(seed) & 0xFFFFFFFF,
                                    1 if train_mode else 0, int(fast_math),
                                    C.c_void_p(struct_done_event.cuda_event) if struct_done_event is not None else None)

@@ -69,8 +69,54 @@ def motif_twisting_function(x0, motif_index_mask, motif_target, alphas_cumprod_t
     return torch.logsumexp(score, dim=0) - torch.log(torch.tensor(float(score.shape[0]), device=x0.device))
 
 
+def get_all_motif_locations(L, segment_lengths, max_offsets=1000, rng=None):
+    """unconditional_smc.py:173-215: every placement of the segments, in order and without overlap, inside 0..L-1, as
+    [(start, end), ...] per placement (end inclusive), in the reference's order -- ascending in the first start, then the second,
+    ...  More than `max_offsets` placements are thinned with one `choice(n, max_offsets, replace=False)` draw (numpy's global
+    generator there; `rng` here, default the same global one)."""
+    import numpy as np
+    k, total = len(segment_lengths), sum(segment_lengths)
+    out = []
+    starts = [0] * k
+
+    def place(seg, first_free):
+        # the segments from `seg` on need this much room; the last admissible start leaves exactly that
+        need = sum(segment_lengths[seg:])
+        for st in range(first_free, L - need + 1):
+            starts[seg] = st
+            if seg + 1 == k:
+                out.append([(s, s + n - 1) for s, n in zip(starts, segment_lengths)])
+            else:
+                place(seg + 1, st + segment_lengths[seg])
+
+    if k and total <= L:
+        place(0, 0)
+    if len(out) > max_offsets:
+        pick = (rng if rng is not None else np.random).choice(len(out), max_offsets, replace=False)
+        out = [out[i] for i in pick]
+    return out
+
+
+def generate_motif_index_mask(motif_target, n_res, max_offsets=1000, rng=None, device=None):
+    """unconditional_smc.py:172-232: bool [n_placement, n_segment, n_res, 3], True over the residues segment j occupies in
+    placement i.  `motif_target`: one entry per segment (anything with a length: its residues)."""
+    locs = get_all_motif_locations(n_res, [len(seg) for seg in motif_target], max_offsets, rng)
+    mask = torch.zeros(len(locs), len(motif_target), n_res, 3, dtype=torch.bool)
+    for i, placement in enumerate(locs):
+        for j, (st, end) in enumerate(placement):
+            mask[i, j, st:end + 1] = True
+    return mask.to(device) if device is not None else mask
+
+
+def placement_masks(motif_index_mask):
+    """[n_placement, n_segment, N, 3] -> [n_placement, N]: the residues any segment covers (what motif_twisting_function takes)."""
+    return motif_index_mask[..., 0].any(dim=1)
+
+
 class TwistedSampler(UnconditionalSampler):
     """params: the UnconditionalSampler's + 'twisting_function': callable (x0_pred [B,N,3] requiring grad, step) -> log p(y | x_t) [B];
+    or, instead, 'motif_target' (list of [n_i, 3] segments: the placements are enumerated with generate_motif_index_mask and the
+    potential is motif_twisting_function over all of them, unconditional_smc.py:303-345); optional 'tausq' with it;
     optional 'noise' [T,B,N,3] (initial draw + one per step, as BaseSampler), 'resample_u' (list of uniforms, tests),
     'guidance_alpha' (default 0.012), 'ess_threshold' (default 0.5), 'last_unguided_steps' (default 50)."""
 
@@ -84,7 +130,14 @@ class TwistedSampler(UnconditionalSampler):
         abar, betas = sched['alphas_cumprod'], sched['betas']
         noise = params.get('noise')
         draw = (lambda k: noise[k].to(self.device)) if noise is not None else (lambda k: torch.randn(B, N, 3, device=self.device))
-        twist = params['twisting_function']
+        twist = params.get('twisting_function')
+        if twist is None:       # the reference's own potential: every placement of the motif segments (:172-232, 303-345)
+            segs = [torch.as_tensor(x, dtype=torch.float32) for x in params['motif_target']]
+            pm = placement_masks(generate_motif_index_mask(segs, N)).to(self.device)
+            tgt = torch.cat(segs).to(self.device)
+            tgt = tgt - tgt.mean(dim=0, keepdim=True)
+            tausq = float(params.get('tausq', 0.012))
+            twist = lambda x0, step: motif_twisting_function(x0, pm, tgt, abar[step], tausq)      # noqa: E731
         alpha = float(params.get('guidance_alpha', 0.012))
         eng = m.model.bind(feats)
         w = pack.flatten_state_dict(m.model.state_dict(), m.model.dims).to(self.device)

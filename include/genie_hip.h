@@ -174,9 +174,9 @@ int genie_sample_loop(genie_handle_t h, genie_stream_t stream, float scale,
 int genie_set_math(genie_handle_t h, int mode);
 int genie_get_math(genie_handle_t h);
 
-/* ---- training step: the two ends around the denoiser -------------------
- * First pieces of the training row (genie/diffusion/genie.py:66-105); the backward pass through the
- * denoiser is not built yet.  Both work on the batch bound with genie_prepare_features. */
+/* ---- training step (genie/diffusion/genie.py:60-120) ---------------------
+ * The two ends around the denoiser first (noising, loss), then the optimizer and the forward + backward pass through the
+ * Denoiser itself (genie_train_forward_backward).  All work on the batch bound with genie_prepare_features. */
 
 /* Forward noising + frames (genie.py:80-87):
  *   trans_s = c_x0[b] x0 + c_z[b] z,   rots_s = compute_frenet_frames(trans_s)
@@ -214,8 +214,9 @@ int genie_adam_step(genie_stream_t stream, size_t n, float* p, const float* g, f
  * inside StructureTransition, structure_net.py:109, structure_transition.py:66) uses counter-based masks derived from `seed`;
  * train_mode = 0 gives the eval-mode forward (what tests/golden/train_grads_n16_b2.npz was recorded in).
  * fast_math: how the GEMMs' f32 operands reach the bf16 matrix pipe -- 0: split in three bf16 pieces (24 significand bits, six MFMAs
- * per product: f32-grade, what the parity tests run), 2: two pieces (16 bits, three MFMAs), 1: plain bf16 (one MFMA: the
- * reference's bf16 autocast). */
+ * per product: f32-grade -- the reference's arithmetic, its Trainer sets no `precision=` (train.py:54-65) and trains in fp32; the
+ * mode every parity test and every quoted figure uses), 2: two pieces (16 bits, three MFMAs), 1: plain bf16 operands (one MFMA;
+ * what a bf16-autocast run would compute -- NARROWER than the reference, offered for BASELINE config 5's "bf16" wording only). */
 typedef struct {
     float tri_dropout, ipa_dropout, transition_dropout;
     uint32_t seed;
@@ -236,8 +237,11 @@ int genie_train_forward_backward(genie_handle_t h, genie_stream_t stream, const 
  * bins of the pair feature net.  `weights`: device blob as for genie_train_forward_backward.  No weight gradients are formed. */
 int genie_denoise_vjp(genie_handle_t h, genie_stream_t stream, const float* weights, const float* trans, const float* rots,
                       const int32_t* timesteps, const int8_t* quat_codes, const float* dz, float* z_out, float* dtrans_out);
-/* Bytes of activations + scratch the last training call holds. */
+/* Bytes of activations + scratch the last training call holds; the kept-for-backward part alone; the algorithmic FLOP (2 M N K per
+ * product) of the GEMMs the last genie_train_forward_backward launched (bench.py's train_step leg prices them with it). */
 size_t genie_train_workspace_bytes(genie_handle_t h);
+size_t genie_train_kept_bytes(genie_handle_t h);
+double genie_train_gemm_flop(genie_handle_t h);
 
 /* The training path's building block, exposed so that it can be checked on its own (tests/test_train_gemm.py; the reference has no
  * counterpart: there these are torch.nn.Linear / einsum calls inside autograd, the files under genie/model).  Device pointers, element strides:

@@ -481,3 +481,74 @@ def test_fused_pair_chains_match_separate_launches(base_engine, monkeypatch):
     assert mdiff(a['z'].cpu()[m], b['z'].cpu()[m]) <= 2e-5 * max(1.0, float(b['z'].abs().max()))
     # the end-of-block mask zeroes padded pairs in both forms
     assert float(a['p'].cpu()[~pm].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('B,N', [(8, 256), (32, 240)])
+def test_fused_pair_chains_match_separate_launches_everywhere_at_full_size(base_engine, monkeypatch, B, N):
+    """The fused chains store z through an LDS staging area with `buffer_store_dwordx4` (fz_store_half), whose data registers need
+    two wait states before they are rewritten -- a regression shows as a few rows of the NEXT piece inside a tile, every few tiles.
+    So: EVERY element of p (and of the first block's taps) of the fused path against the separate launches (GENIE_NO_PAIR_FUSE, which
+    shares none of that store code), at the headline size (N = 256, batch 8) and at config 3's batch 32 with N = 240 (not a multiple
+    of 32: partial tiles), compared on the device."""
+    f = O.empty_features([N] * B)
+    g = torch.Generator().manual_seed(100 + B)
+    x = torch.randn(B, N, 3, generator=g) * 6
+    base_engine.set_math('hx')
+    base_engine.bind_features(f)
+    r = base_engine.frenet(x)
+    ts = torch.randint(1, 1001, (B,), generator=g).int()
+    taps = ('p', 'p_layer0', 'p_trimul_out0')
+    monkeypatch.delenv('GENIE_NO_PAIR_FUSE', raising=False)
+    a = base_engine.denoise(x, r, ts, None, taps=taps)
+    a2 = base_engine.denoise(x, r, ts, None, taps=('p',))       # the other tile direction (launch parity alternates)
+    monkeypatch.setenv('GENIE_NO_PAIR_FUSE', '1')
+    b = base_engine.denoise(x, r, ts, None, taps=taps)
+    monkeypatch.delenv('GENIE_NO_PAIR_FUSE', raising=False)
+    for k in taps:
+        assert torch.isfinite(a[k]).all(), k
+        scale = max(1.0, float(b[k].abs().max()))
+        d = (a[k] - b[k]).abs()
+        worst = float(d.max())
+        assert worst <= 2e-5 * scale, (k, worst, scale, int((d > 2e-5 * scale).sum()))
+    assert float((a2['p'] - b['p']).abs().max()) <= 2e-5 * max(1.0, float(b['p'].abs().max()))
+    assert float((a['z'] - b['z']).abs().max()) <= 2e-5 * max(1.0, float(b['z'].abs().max()))
+    del a, a2, b
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('math', MATH_MODES)
+def test_heavy_tailed_pair_weights_and_large_layernorm_gains(math):
+    """What trained checkpoints look like and the synthetic recipe does not: every pair-stack matrix carries a few entries 50x its
+    typical size, LayerNorm gains reach 10.  The split-f16 path takes its operand scales from bounds over the weights (hx_bound,
+    Cauchy-Schwarz over the LN-folded rows) -- outliers inflate those bounds, which must cost neither range nor the 1e-4 bar."""
+    from genie2_amd.engine import GenieEngine
+    dims = O.small_dims()
+    sd = O.synthetic_state_dict(dims, seed=15)
+    g = torch.Generator().manual_seed(77)
+    for k in sorted(sd):
+        if not k.startswith('pair_transform_net'):
+            continue
+        if 'layer_norm' in k and k.endswith('weight'):
+            sd[k] = sd[k] * torch.exp(torch.rand(sd[k].shape, generator=g) * 2.302585)            # gains spread over 1 .. 10
+        elif k.endswith('weight') and sd[k].dim() == 2:
+            w = sd[k].clone()
+            n_out = max(3, w.numel() // 2000)
+            idx = torch.randint(0, w.numel(), (n_out,), generator=g)
+            w.view(-1)[idx] = w.view(-1)[idx] * 50.0
+            # keep the layer's output scale where it was, so that the test stresses ranges, not the network's conditioning
+            sd[k] = w * (sd[k].norm() / w.norm())
+    f = O.empty_features([48, 40])
+    trans = 2.5 * torch.randn(2, 48, 3, generator=g)
+    fr = O.prepare_features(f)
+    rots = O.compute_frenet_frames(trans, fr['chain_index'], fr['residue_mask'])
+    ts = torch.tensor([60, 3], dtype=torch.int32)
+    ref = O.denoiser_forward(sd, dims, rots, trans, ts, f, 'closed')
+    assert torch.isfinite(ref['p']).all()
+    eng = GenieEngine(dims, sd, 'cuda:0', math=math)
+    eng.bind_features(f)
+    out = eng.denoise(trans, rots, ts, None, taps=('p',))
+    m = fr['residue_mask'].unsqueeze(-1).float()
+    print('max|p|', float(ref['p'].abs().max()), 'dp', mdiff(out['p'], ref['p']), 'dz', mdiff(out['z'].cpu() * m, ref['z'] * m))
+    assert mdiff(out['p'], ref['p']) <= 1e-4 * max(1.0, float(ref['p'].abs().max()))
+    assert mdiff(out['z'].cpu() * m, ref['z'] * m) <= 1e-4 * max(1.0, float(ref['z'].abs().max()))
+    eng.close()

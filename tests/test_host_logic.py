@@ -429,3 +429,141 @@ def test_smc_helpers_follow_the_quoted_reference_lines():
     assert abs(float(compute_ess_from_log_w(lw)) - 1.0 / (0.25 + 0.0625 * 2)) < 1e-5
     assert torch.allclose(torch.exp(normalize_log_weights(lw + 100.0, 0)), torch.tensor([0.5, 0.25, 0.25]), atol=1e-6)
     assert abs(float(compute_ess_from_log_w(torch.zeros(8))) - 8.0) < 1e-5
+
+
+def _tiny_batch(lengths=(20, 17), pad=24, seed=5, motif=False):
+    from genie2_amd import features as F
+    g = torch.Generator().manual_seed(seed)
+    feats = []
+    for n in lengths:
+        f = F.create_empty_np_features([n])
+        f['atom_positions'] = (torch.randn(n, 3, generator=g) * 4).numpy()
+        feats.append(F.pad_np_features(f, 1, pad))
+    batch = {k: torch.as_tensor(np.stack([f[k] for f in feats])) for k in feats[0]}
+    if motif:       # sample 0 carries a 4-residue motif (conditioned), sample 1 stays unconditional
+        batch['fixed_sequence_mask'][0, 2:6] = True
+    return batch
+
+
+def test_checkpoint_carries_adam_state_and_resume_is_bit_exact(tmp_path):
+    """Lightning's ModelCheckpoint keeps `optimizer_states` next to the weights (train.py:35-39) and a new run opens the next
+    version_* directory: two steps -> save_checkpoint(trainer=) -> load_model (latest version / epoch, model_io.py:84-137) ->
+    GenieTrainer.resume -> a third step gives the weights of the uninterrupted three-step run BIT FOR BIT (gradients from the
+    oracle's autograd through the CPU test backend).  The file holds tensors and plain containers only (weights_only=True) and its
+    optimizer entry is what torch.optim.Adam.load_state_dict accepts over the Denoiser's parameters in state_dict order."""
+    from _oracle_backend import OracleBackend
+    from genie2_amd.diffusion import load_model, save_checkpoint, get_versions, get_epochs
+    from genie2_amd.training import GenieTrainer
+    from genie2_amd import pack
+    root = tmp_path / 'runs'
+    (root / 'tiny').mkdir(parents=True)
+    (root / 'tiny' / 'configuration').write_text('name tiny\nnumPairTransformLayers 1\nnumStructureLayers 1\nnumTimesteps 50\nmaximumNumResidues 32\nlearningRate 0.001\n')
+    batch = _tiny_batch()
+
+    def steps(tr, which):
+        for k in which:
+            torch.manual_seed(1000 + k)          # the step's draws of s and z (genie.py:72-79) come from the global generator
+            tr.training_step(batch)
+            tr.optimizer_step()
+
+    g_full = load_model(str(root), 'tiny')                # no checkpoint yet: the untrained default
+    full = GenieTrainer(g_full, backend=OracleBackend(g_full.model.dims), train_mode=False)
+    steps(full, (0, 1, 2))
+
+    g_a = load_model(str(root), 'tiny')
+    a = GenieTrainer(g_a, backend=OracleBackend(g_a.model.dims), train_mode=False)
+    steps(a, (0, 1))
+    a.epoch = 4
+    ck = root / 'tiny' / 'version_0' / 'checkpoints' / 'epoch=3.ckpt'
+    save_checkpoint(g_a, str(ck), epoch=3, global_step=a.step, trainer=a)
+    steps(a, (2,))                                        # training goes on after a checkpoint (the module / backend were not touched)
+    assert torch.equal(a.w, full.w)
+
+    blob = torch.load(str(ck), map_location='cpu', weights_only=True)
+    assert {'state_dict', 'optimizer_states', 'epoch', 'global_step', 'lr_schedulers'} <= set(blob)
+    layout = pack.weight_layout(g_a.model.dims)
+    assert list(blob['state_dict']) == ['model.' + k for k, _ in layout]
+    params = [torch.nn.Parameter(torch.zeros(shape)) for _, shape in layout]
+    opt = torch.optim.Adam(params, lr=1e-4)
+    opt.load_state_dict(blob['optimizer_states'][0])
+    assert float(opt.state[params[0]]['step']) == 2.0 and opt.param_groups[0]['lr'] == 1e-3
+    assert opt.state[params[3]]['exp_avg'].shape == params[3].shape
+
+    assert get_versions(str(root), 'tiny') == [0] and get_epochs(str(root), 'tiny', 0) == [3]
+    g_b = load_model(str(root), 'tiny')
+    assert g_b.checkpoint_info['epoch'] == 3 and g_b.checkpoint_info['global_step'] == 2
+    b = GenieTrainer(g_b, backend=OracleBackend(g_b.model.dims), train_mode=False)
+    b.resume(g_b.checkpoint_info)
+    assert b.step == 2 and b.epoch == 4
+    steps(b, (2,))
+    assert torch.equal(b.w, full.w)                       # bit for bit
+    # a weights-only checkpoint (what the reference's own resume amounts to) restarts Adam
+    save_checkpoint(g_a, str(root / 'tiny' / 'version_1' / 'checkpoints' / 'epoch=0.ckpt'), epoch=0)
+    g_c = load_model(str(root), 'tiny')
+    c = GenieTrainer(g_c, backend=OracleBackend(g_c.model.dims), train_mode=False)
+    c.resume(g_c.checkpoint_info)
+    assert c.step == 0 and c.epoch == 1 and float(c.m.abs().max()) == 0.0
+
+
+def test_training_loss_log_follows_the_reference_split():
+    """genie.py:106-118: per step unweighted / weighted loss; per sample motif + scaffold losses when the sample is conditioned,
+    the unconditional loss otherwise, each over its own residue count."""
+    from _oracle_backend import OracleBackend, small_config
+    from genie2_amd.diffusion import Genie, mse
+    from genie2_amd.training import GenieTrainer, format_log
+    from genie2_amd.features import prepare_tensor_features
+    genie = Genie(small_config())
+    tr = GenieTrainer(genie, backend=OracleBackend(genie.model.dims), train_mode=False)
+    batch = _tiny_batch(motif=True)
+    torch.manual_seed(3)
+    tr.training_step(batch)
+    log = tr.loss_log()
+    assert len(log['motif_mse_loss']) == 1 and len(log['scaffold_mse_loss']) == 1 and len(log['unconditional_mse_loss']) == 1
+    f = prepare_tensor_features(batch)
+    call = tr.backend.calls[-1]
+    zp = tr.last['z']
+    cm = f['residue_mask'] * f['fixed_sequence_mask']
+    im = f['residue_mask'] * ~f['fixed_sequence_mask']
+    cond = mse(zp, call['z'], cm, aggregate='sum') / cm.sum(-1)
+    infill = mse(zp, call['z'], im, aggregate='sum') / im.sum(-1)
+    assert abs(log['motif_mse_loss'][0] - float(cond[0])) < 1e-5 and abs(log['scaffold_mse_loss'][0] - float(infill[0])) < 1e-5
+    assert abs(log['unconditional_mse_loss'][0] - float(infill[1])) < 1e-5
+    line = format_log(0, 1, log)
+    assert all(k in line for k in ('unweighted_loss', 'weighted_loss', 'motif_mse_loss', 'scaffold_mse_loss', 'unconditional_mse_loss'))
+
+
+def test_motif_placements_enumerate_like_the_reference():
+    """unconditional_smc.py:172-232 on hand-enumerable cases: placements in ascending order of the segment starts, non-overlapping,
+    in order, inside the sequence; the mask layout [n_placement, n_segment, N, 3]; thinning to max_offsets with one choice() draw."""
+    from genie.sampler.unconditional_smc import get_all_motif_locations, generate_motif_index_mask
+    from genie2_amd.smc import placement_masks
+    assert get_all_motif_locations(4, [2]) == [[(0, 1)], [(1, 2)], [(2, 3)]]
+    assert get_all_motif_locations(5, [2, 1]) == [[(0, 1), (2, 2)], [(0, 1), (3, 3)], [(0, 1), (4, 4)], [(1, 2), (3, 3)], [(1, 2), (4, 4)],
+                                                  [(2, 3), (4, 4)]]
+    assert get_all_motif_locations(3, [2, 2]) == [] and get_all_motif_locations(4, [2, 2]) == [[(0, 1), (2, 3)]]
+    # count = C(L - total + k, k); order = lexicographic in the starts
+    import math
+    locs = get_all_motif_locations(12, [3, 2, 2])
+    assert len(locs) == math.comb(12 - 7 + 3, 3)
+    starts = [tuple(s for s, _ in pl) for pl in locs]
+    assert starts == sorted(starts) and len(set(starts)) == len(starts)
+    for pl in locs:
+        assert pl[0][0] >= 0 and pl[-1][1] <= 11 and all(pl[i][1] < pl[i + 1][0] for i in range(2))
+        assert [e - s + 1 for s, e in pl] == [3, 2, 2]
+    m = generate_motif_index_mask([torch.zeros(2, 3), torch.zeros(1, 3)], 5)
+    assert m.shape == (6, 2, 5, 3) and m.dtype == torch.bool
+    assert m[3, 0, :, 0].tolist() == [False, True, True, False, False] and m[3, 1, :, 1].tolist() == [False, False, False, True, False]
+    assert placement_masks(m).sum(-1).tolist() == [3] * 6
+    # more placements than max_offsets: one numpy choice(n, max_offsets, replace=False) picks which survive
+    rng = np.random.RandomState(4)
+    few = get_all_motif_locations(12, [3, 2, 2], max_offsets=10, rng=rng)
+    pick = np.random.RandomState(4).choice(len(locs), 10, replace=False)
+    assert few == [locs[i] for i in pick]
+
+
+def test_train_entry_point_parses_the_reference_flags():
+    """genie/train.py is an entry point like the reference's (train.py:70-81): -c required, -d / -n / -t accepted."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'genie', 'train.py'), '--help'], capture_output=True, text=True)
+    assert r.returncode == 0 and all(f in r.stdout for f in ('--devices', '--num_nodes', '--config', '--test'))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'genie', 'train.py')], capture_output=True, text=True)
+    assert r.returncode == 2 and 'config' in r.stderr

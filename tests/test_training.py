@@ -385,3 +385,259 @@ def test_two_structure_blocks_share_weights_in_both_paths():
     assert abs(float(out['weighted_loss']) - float(lo['weighted_loss'].detach())) <= 1e-4 * float(lo['weighted_loss'].detach())
     check_grads(split(out['grads'].cpu(), dims), gref)
     eng.close()
+
+
+def _np_batch(lengths, pad, seed=3, scale=5.0):
+    from genie2_amd import features as F
+    g = torch.Generator().manual_seed(seed)
+    feats = []
+    for n in lengths:
+        ff = F.create_empty_np_features([n])
+        ff['atom_positions'] = (torch.randn(n, 3, generator=g) * scale).numpy()
+        feats.append(F.pad_np_features(ff, 1, pad))
+    return {k: torch.as_tensor(np.stack([ff[k] for ff in feats])) for k in feats[0]}
+
+
+def test_training_continues_after_sync_to_model_and_checkpoint(tmp_path):
+    """A checkpoint in the middle of training: sync_to_model() reloads the module (which drops its engine) and the trainer must keep
+    going on the new one; save_checkpoint(trainer=) does not touch the module at all.  The loss on a fixed batch keeps falling
+    across both, and a second fit() call works."""
+    from _oracle_backend import small_config
+    from genie2_amd.diffusion import Genie, save_checkpoint
+    from genie2_amd.training import GenieTrainer
+    cfg = small_config(n_pair=1, n_struct=2, n_timestep=50)
+    genie = Genie(cfg).to('cuda:0')
+    tr = GenieTrainer(genie, train_mode=False, seed=5)
+    tr.lr = 2e-3
+    batch = _np_batch((24, 19), 24)
+    fixed_s = torch.tensor([11, 40])
+    fixed_z = torch.randn(2, 24, 3, generator=torch.Generator().manual_seed(1))
+    orig_randint, orig_randn_like = torch.randint, torch.randn_like
+    torch.randint = lambda *a, **k: fixed_s - 1
+    torch.randn_like = lambda x: fixed_z.to(x.device)
+    try:
+        losses = []
+        for _ in range(3):
+            losses.append(float(tr.training_step(batch))); tr.optimizer_step()
+        eng_before = tr.backend.engine
+        save_checkpoint(genie, str(tmp_path / 'version_0' / 'checkpoints' / 'epoch=0.ckpt'), epoch=0, global_step=tr.step, trainer=tr)
+        assert tr.backend.engine is eng_before and eng_before._h                 # untouched
+        for _ in range(2):
+            losses.append(float(tr.training_step(batch))); tr.optimizer_step()
+        tr.sync_to_model()                                                        # drops the engine; the backend fetches the new one
+        assert eng_before._h is None and tr.backend.engine is not eng_before
+        for _ in range(3):
+            losses.append(float(tr.training_step(batch))); tr.optimizer_step()
+        # sampling through the module between training steps must re-bind (the trainer bound its own batch behind the module's back)
+        z1 = genie.model.engine()
+        assert genie.model._bound is None and z1 is tr.backend.engine
+        tr.fit([batch, batch], n_epoch=1)
+        losses.append(float(tr.training_step(batch)))
+    finally:
+        torch.randint, torch.randn_like = orig_randint, orig_randn_like
+    assert all(np.isfinite(losses)) and losses[-1] < losses[4] < losses[0], losses
+    ck = torch.load(str(tmp_path / 'version_0' / 'checkpoints' / 'epoch=0.ckpt'), weights_only=True)
+    assert int(float(ck['optimizer_states'][0]['state'][0]['step'])) == 3
+
+
+_RCCL_WORKER = r'''
+import os, sys, json, torch, torch.distributed as td, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 'tests'))
+from genie2_amd.config import Config
+from genie2_amd.diffusion import Genie
+from genie2_amd.training import GenieTrainer
+from genie2_amd import features as F
+torch.cuda.set_device(0)
+td.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+cfg = Config()                                              # the base model
+cfg.io['max_n_res'] = 128
+g = torch.Generator().manual_seed(3)
+feats = []
+for n in (96, 81):
+    ff = F.create_empty_np_features([n])
+    ff['atom_positions'] = (torch.randn(n, 3, generator=g) * 6).numpy()
+    feats.append(F.pad_np_features(ff, 1, 96))
+batch = {k: torch.as_tensor(np.stack([ff[k] for ff in feats])) for k in feats[0]}
+fixed_s = torch.tensor([400, 33]); fixed_z = torch.randn(2, 96, 3, generator=g)
+torch.randint = lambda *a, **k: fixed_s - 1
+torch.randn_like = lambda x: fixed_z.to(x.device)
+res = {}
+def run(kind):
+    genie = Genie(cfg).to('cuda:0')                         # random_state_dict(seed 0): the same weights every time
+    tr = GenieTrainer(genie, train_mode=False, force_overlap=(kind != 'plain'))
+    tr.lr = 1e-3
+    info = {}
+    if kind == 'sim2':      # two ranks holding the same gradients: the "sum" doubles, the mean restores -- IF the reduction saw final gradients
+        tr._world = lambda: 2
+        def fake(t):
+            t.mul_(2.0)     # on the current stream: the side stream for the tail bucket
+            return None
+        tr._all_reduce = fake
+    grads = []
+    for step in range(2):
+        tr.training_step(batch)
+        end = torch.cuda.Event(enable_timing=True); end.record()        # after the whole backward pass on the compute stream
+        tr.sync_gradients()
+        torch.cuda.synchronize()
+        if kind != 'plain':
+            info.setdefault('struct_to_end_ms', []).append(tr._event.elapsed_time(end))
+            info.setdefault('tail_done_to_end_ms', []).append(tr._tail_done.elapsed_time(end))
+        grads.append(tr.g.clone())
+        tr.step += 1
+        tr.backend.adam(tr.w, tr.g, tr.m, tr.v, tr.lr, tr.step)
+    torch.cuda.synchronize()
+    return tr, grads, info
+plain, g_plain, _ = run('plain')
+ov, g_ov, info_ov = run('overlap')
+sim, g_sim, info_sim = run('sim2')
+so = plain.struct_offset
+def rel(a, b):
+    return float((a - b).norm() / b.norm())
+res['struct_offset'] = so; res['n'] = plain.w.numel()
+res['grad_rel_overlap'] = [rel(a, b) for a, b in zip(g_ov, g_plain)]
+res['grad_rel_sim2_tail'] = [rel(a[so:], b[so:]) for a, b in zip(g_sim, g_plain)]
+res['grad_rel_sim2_head'] = [rel(a[:so], b[:so]) for a, b in zip(g_sim, g_plain)]
+res['w_maxdiff_overlap'] = float((ov.w - plain.w).abs().max()); res['w_meandiff_overlap'] = float((ov.w - plain.w).abs().mean())
+res['w_maxdiff_sim2'] = float((sim.w - plain.w).abs().max()); res['w_meandiff_sim2'] = float((sim.w - plain.w).abs().mean())
+res['timing_overlap'] = info_ov; res['timing_sim2'] = info_sim
+res['event_handle_nonzero'] = bool(ov._event.cuda_event)
+td.barrier()
+td.destroy_process_group()
+open(sys.argv[2], 'w').write(json.dumps(res))
+'''
+
+
+def test_rccl_one_rank_bucketed_all_reduce_on_the_device(tmp_path):
+    """Config 5's exchange step on the GPU, in a fresh child process under init_process_group('nccl', world_size=1): the trainer's
+    overlap path -- struct_done_event recorded by the library inside the backward pass, the side stream waiting on it, the
+    structure_net bucket's all_reduce (RCCL) enqueued there, the head bucket after the pass, the mean, Adam -- against the same two
+    steps without any of it.  (Weight gradients are float-atomic sums: runs agree to f32 rounding, not bit for bit; Adam turns a
+    rounding-level gradient into a full lr step, hence max vs mean bounds on the weights.)  `sim2` replaces the collective by what
+    two ranks with equal gradients would see (sum = 2 g) with the mean over 2: were the tail bucket reduced before its gradients
+    are final (the event missing or unrecorded) it would come out halved.  Event timestamps: the structure gradients are final,
+    and the tail bucket's reduction has completed, before the backward pass ends."""
+    import json, os, subprocess, sys, tempfile
+    from conftest import ROOT
+    with tempfile.NamedTemporaryFile('w', suffix='.py', delete=False) as fh:
+        fh.write(_RCCL_WORKER)
+    out = str(tmp_path / 'res.json')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29561', RANK='0', WORLD_SIZE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, fh.name, ROOT, out], env=env, capture_output=True, text=True, timeout=900)
+    os.unlink(fh.name)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    r = json.load(open(out))
+    print(r)
+    assert r['event_handle_nonzero']
+    assert max(r['grad_rel_overlap']) <= 1e-5
+    assert max(r['grad_rel_sim2_tail']) <= 1e-5 and max(r['grad_rel_sim2_head']) <= 1e-5       # 0.5 if the tail was reduced too early
+    assert r['w_maxdiff_overlap'] <= 2.5e-3 and r['w_meandiff_overlap'] <= 1e-6
+    assert r['w_maxdiff_sim2'] <= 2.5e-3 and r['w_meandiff_sim2'] <= 1e-6
+    for t in (r['timing_overlap'], r['timing_sim2']):
+        assert min(t['struct_to_end_ms']) > 0.5, t          # the pair stack's backward pass runs after the structure gradients are final
+        assert min(t['tail_done_to_end_ms']) > 0.0, t       # ... and the tail bucket's reduction finished under it
+
+
+def test_training_step_at_n256_batch2_base_model():
+    """Config 5's full size (L <= 256): the base model at N = 256, batch 2 (ragged: 256 and 231).  z and the losses against the
+    oracle's no-grad forward; the size-independent property of the mean loss: grads(batch of 2) = 1/2 (grads(sample 0) +
+    grads(sample 1)) per tensor; finite; workspace reported."""
+    from genie2_amd.engine import GenieEngine
+    dims = dict(O.BASE_DIMS)
+    sd = O.synthetic_state_dict(dims, seed=3)
+    f, z, g = _case(31, [256, 231], motif=True)
+    sched = O.training_schedule(dims['n_timestep'])
+    s = torch.tensor([300, 950])
+    fr = O.prepare_features(f)
+    trans, rots = O.q_sample(f['atom_positions'], s, z, fr['chain_index'], fr['residue_mask'], sched)
+    with torch.no_grad():
+        zo = O.denoiser_forward(sd, dims, rots, trans, s.int(), f, 'closed')['z']
+        lo = O.training_loss(zo, z, fr, 2.0)
+    eng = GenieEngine(dims, sd, 'cuda:0')
+    w = flat(sd, dims).cuda()
+    eng.bind_features(f)
+    out = eng.train_forward_backward(w, trans, rots, s.int(), z, 2.0, train_mode=False)
+    m = fr['residue_mask'].unsqueeze(-1).float()
+    assert float(((out['z'].cpu() - zo) * m).abs().max()) <= 2e-4 * max(1.0, float(zo.abs().max()))
+    for k in ('weighted_loss', 'unweighted_loss'):
+        assert abs(float(out[k]) - float(lo[k])) <= 1e-4 * float(lo[k]), k
+    assert float((out['condition_losses'].cpu() - lo['condition_losses']).abs().max()) <= 1e-3 * max(1.0, float(lo['condition_losses'].abs().max()))
+    gb = out['grads'].clone()
+    assert torch.isfinite(gb).all()
+    ws = eng.workspace_bytes(), int(eng.lib.genie_train_workspace_bytes(eng._h)), int(eng.lib.genie_train_kept_bytes(eng._h))
+    print('workspace: sampling %.2f GiB, training %.2f GiB (kept %.2f)' % tuple(x / 2 ** 30 for x in ws))
+    assert ws[1] > ws[2] > 0
+    acc = torch.zeros_like(gb)
+    for b in range(2):
+        fb = {k: (v[b:b + 1] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == 2 else v) for k, v in f.items()}
+        eng.bind_features(fb)
+        o1 = eng.train_forward_backward(w, trans[b:b + 1], rots[b:b + 1], s[b:b + 1].int(), z[b:b + 1], 2.0, train_mode=False)
+        acc += 0.5 * o1['grads']
+    worst = check_grads(split(gb.cpu(), dims), split(acc.cpu(), dims), tol=2e-3)
+    print('worst relative difference batch vs mean of singles', worst)
+    eng.close()
+
+
+def test_bf16_operand_mode_points_the_same_way():
+    """fast_math = 1 (plain bf16 operands: NARROWER than the reference, which trains in fp32) and 2 (two bf16 pieces): the whole
+    gradient vector against the f32-grade mode at the base model, N = 64 -- cosine and relative norm -- so that the modes are
+    checked as what they are, reduced-precision versions of the same gradient, not only per tensor at tol 0.25."""
+    from genie2_amd.engine import GenieEngine
+    dims = dict(O.BASE_DIMS)
+    sd = O.synthetic_state_dict(dims, seed=3)
+    f, z, g = _case(41, [64, 50])
+    sched = O.training_schedule(dims['n_timestep'])
+    s = torch.tensor([500, 120])
+    fr = O.prepare_features(f)
+    trans, rots = O.q_sample(f['atom_positions'], s, z, fr['chain_index'], fr['residue_mask'], sched)
+    eng = GenieEngine(dims, sd, 'cuda:0')
+    eng.bind_features(f)
+    w = flat(sd, dims).cuda()
+    ref = eng.train_forward_backward(w, trans, rots, s.int(), z, 1.0, train_mode=False, fast_math=0)
+    gr, lr_ = ref['grads'].double().clone(), float(ref['weighted_loss'])
+    for mode, cos_min, rel_max, loss_tol in ((2, 0.99999, 5e-3, 1e-4), (1, 0.995, 0.1, 2e-2)):
+        o = eng.train_forward_backward(w, trans, rots, s.int(), z, 1.0, train_mode=False, fast_math=mode)
+        gm = o['grads'].double()
+        cos = float((gm * gr).sum() / (gm.norm() * gr.norm()))
+        rel = float((gm - gr).norm() / gr.norm())
+        print('fast_math', mode, 'cosine', cos, 'relative', rel, 'loss', float(o['weighted_loss']), lr_)
+        assert cos >= cos_min and rel <= rel_max, (mode, cos, rel)
+        assert abs(float(o['weighted_loss']) - lr_) <= loss_tol * lr_
+    eng.close()
+
+
+def test_train_cli_runs_twice_under_torch_distributed_run(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 1 ... -m genie2_amd.train -c <config> --force_overlap`: the documented
+    multi-GPU command rehearsed at one rank on the device (RCCL communicator, DistributedSampler-free single rank, bucketed
+    all-reduce path forced).  First run: version_0/checkpoints/epoch=0.ckpt, epoch=1.ckpt.  Second run: resumes from epoch=1 (Adam
+    step restored), opens version_1 and writes epoch=2.ckpt, epoch=3.ckpt -- nothing of version_0 is overwritten (train.py:22-39,
+    model_io.py:84-137)."""
+    import os, subprocess, sys
+    from conftest import ROOT, GOLDEN
+    data = tmp_path / 'pdbs'
+    data.mkdir()
+    src = open(os.path.join(GOLDEN, 'dataset_100_0.pdb')).read()
+    for name in ('a100', 'b100', 'c100', 'd100'):
+        (data / (name + '.pdb')).write_text(src)
+    root = tmp_path / 'runs'
+    cfgp = tmp_path / 'train.config'
+    cfgp.write_text('\n'.join(['name tiny', 'rootDirectory ' + str(root), 'dataDirectory ' + str(data), 'numPairTransformLayers 1', 'numStructureLayers 2',
+                               'numTimesteps 50', 'maximumNumResidues 128', 'minimumNumResidues 20', 'numEpoches 2', 'batchSize 2', 'logEverySteps 1',
+                               'checkpointEveryEpoches 1', 'learningRate 0.001']) + '\n')
+    (root / 'tiny').mkdir(parents=True)
+    (root / 'tiny' / 'configuration').write_text(cfgp.read_text())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONPATH=ROOT)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', '29571',
+           '-m', 'genie2_amd.train', '-c', str(cfgp), '--force_overlap']
+    r1 = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r1.returncode == 0, (r1.stdout[-2000:], r1.stderr[-4000:])
+    ck0 = root / 'tiny' / 'version_0' / 'checkpoints'
+    assert sorted(os.listdir(ck0)) == ['epoch=0.ckpt', 'epoch=1.ckpt']
+    assert 'weighted_loss' in r1.stdout and ('unconditional_mse_loss' in r1.stdout or 'motif_mse_loss' in r1.stdout)
+    before = {n: (ck0 / n).read_bytes() for n in os.listdir(ck0)}
+    r2 = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r2.returncode == 0, (r2.stdout[-2000:], r2.stderr[-4000:])
+    assert 'Resuming at epoch 2 (Adam step 4)' in r2.stdout, r2.stdout[-2000:]
+    assert sorted(os.listdir(root / 'tiny' / 'version_1' / 'checkpoints')) == ['epoch=2.ckpt', 'epoch=3.ckpt']
+    assert {n: (ck0 / n).read_bytes() for n in os.listdir(ck0)} == before
+    last = torch.load(str(root / 'tiny' / 'version_1' / 'checkpoints' / 'epoch=3.ckpt'), weights_only=True)
+    assert last['epoch'] == 3 and last['global_step'] == 8 and int(float(last['optimizer_states'][0]['state'][0]['step'])) == 8
