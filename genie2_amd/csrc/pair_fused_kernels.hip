@@ -39,13 +39,25 @@
 #ifndef FZ_SAFE
 #define FZ_SAFE 0
 #endif
+#ifndef FZ_ASYM
+#define FZ_ASYM 0          // 1: a stage's LDS-DMA pieces are all issued by waves 4..7
+#endif
+#ifndef FZ_BIASPRE
+#define FZ_BIASPRE 0       // 1: a transition stage's initial accumulators (b1 block) are fetched under the previous stage's second GEMM
+#endif
+#ifndef FZ_KO
+#define FZ_KO 0            // developer knock-outs of the transition stage (timing only, results wrong): 1 no ReLU / split, 2 no fragment re-reads, 4 no barrier / wait, 8 no weight DMA
+#endif
+#ifndef FZ_ZEARLY
+#define FZ_ZEARLY 0        // 1: the first channel half of z is requested at the tile's start (behind the x loads), not inside the first stage
+#endif
 #define FZ_FULL_WAIT(bit) do { if (FZ_SAFE & (bit)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); else asm volatile("" ::: "memory"); } while (0)
 
 // developer builds (-DFZ_TS): s_memtime stamps of every wave of work-group 0, read with tests/devtools/ts_fused.py; none in the product
 #ifdef FZ_TS
 __device__ unsigned long long g_fz_ts[16][2048];      // [variant * 8 + wave]
 extern "C" int genie_fz_debug_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fz_ts), sizeof(unsigned long long) * 16 * 2048); }
-#define FZ_TS_DECL() const bool ts_on = blockIdx.x == 0; unsigned long long* ts_p = g_fz_ts[(HAS_T ? 8 : 0) + (threadIdx.x >> 6)]; int ts_n = 0
+#define FZ_TS_DECL() const bool ts_on = blockIdx.x == 0 && HAS_P;      /* (the last block's chain without projections would overwrite chain B's slots) */ unsigned long long* ts_p = g_fz_ts[(HAS_T ? 8 : 0) + (threadIdx.x >> 6)]; int ts_n = 0
 #define FZ_STAMP() do { if (ts_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0 && ts_n < 2048) ts_p[ts_n] = t_; ++ts_n; } } while (0)
 #else
 #define FZ_TS_DECL()
@@ -166,11 +178,23 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
     const int sstride = NP * NP * 4;                         // bytes per channel of a channel-major image
     const int zstride = COL ? N * 512 : 512;                 // bytes between consecutive pairs of a tile
     auto issue = [&](int s, int buf) {
+#if FZ_ASYM
+        // the whole stage is requested by waves 4..7 (8 pieces each): their SIMD partners 0..3 start the stage's MFMAs at once, and the
+        // two waves of a SIMD stay half a phase apart for the rest of the stage -- one's VALU phases sit beside the other's MFMAs
+        if (wave >= 4) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int p = 8 * (wave - 4) + q;
+                hx_dma(rw, smb + buf * HX_STAGE_BYTES + p * 1024, lane16, s * HX_STAGE_BYTES + p * 1024);
+            }
+        }
+#else
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int p = 4 * wave + q;
             hx_dma(rw, smb + buf * HX_STAGE_BYTES + p * 1024, lane16, s * HX_STAGE_BYTES + p * 1024);
         }
+#endif
     };
     unsigned char* zt = smb + 2 * HX_STAGE_BYTES + 6144 + wave * HX_ZT_BYTES;
     // wave-tile 8 tile + wave (clamped): z byte offset of its first row, valid rows, channel-major element offset of (channel 0, pair 0)
@@ -253,11 +277,26 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
         FZ_STAMP();
 #pragma unroll
         for (int c = (HAS_T && FZ_XPRE) ? 4 : 0; c < 8; ++c) FZ_XLOAD(c, cmoff);      // (chain A: all of x here -- no phase of it has room to fetch ahead)
+#if FZ_ZEARLY
+        // z: its second channel half (prefetched by the previous tile) moves from the staging area to registers now, and the first half is
+        // requested right behind the x loads: it lands under the LayerNorm of x and the first stage instead of being waited for at that
+        // stage's end
+        float4 rz1[8];                                        // chunks 4..7
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fz_zt_chunk(rz1[2 * q], rz1[2 * q + 1], zt, pl_t, h_t, q);
+        hx_lds_done();
+        hx_zt_dma(rz, zt, lane_t, zsoff, zstride, znv, 0);
+#endif
         const float msk = (pl < nvalid) ? A.rmask[b * N + line] * A.rmask[b * N + t0i + pl] : 0.f;
         const bool more = tile + (int)gridDim.x < n_tiles;
         int n_zsoff = 0, n_nv = 1, n_cmoff = 0;
         if (more) tile_geom(tile + gridDim.x, n_zsoff, n_nv, n_cmoff);
+#if FZ_ZEARLY
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // x has landed: at most the 8 z pieces (and the mask loads) are younger
+        __builtin_amdgcn_sched_barrier(0);
+#else
         hx_vm_done();
+#endif
         FZ_STAMP();
         f32x16 v[4];                                          // the tile's running value: update -> z' -> (z'' accumulators) -> z''
 
@@ -270,7 +309,9 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
             // z: its second channel half (prefetched by the previous tile) goes to registers, its first half is then fetched into the
             // staging area and STAYS there until the gates are done -- chunks of it are read where they are used (32 live registers
             // instead of 64 through the tightest stages).
+#if !FZ_ZEARLY
             float4 rz1[8];                                    // chunks 4..7
+#endif
             float zsh = 0.f, zs1 = 0.f, zs2 = 0.f;            // shifted sums for the LayerNorm statistics
 #pragma unroll
             for (int half = 0; half < 2; ++half) {            // stages 0, 1: update accumulators of channel blocks 2 half, 2 half + 1
@@ -293,11 +334,13 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
                     MFH3(f1, f1l, xh[kc], xl[kc], v[2 * half + 1]);
                     PIPE_FENCE();
                     f0 = n0; f0l = n0l; f1 = n1; f1l = n1l;
+#if !FZ_ZEARLY
                     if (half == 0 && kc == 0) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) fz_zt_chunk(rz1[2 * q], rz1[2 * q + 1], zt, pl_t, h_t, q);
                     }
                     if (half == 0 && kc == 2) { hx_lds_done(); hx_zt_dma(rz, zt, lane_t, zsoff, zstride, znv, 0); }   // first channel half of z
+#endif
                     // LayerNorm statistics of z between this stage's MFMAs, as sums shifted by the row's first element
                     if (half == 1 && kc == 1) {
                         zsh = __shfl(rz1[0].x, lane & 31);         // (the same shift in both half-waves of a row)
@@ -390,21 +433,29 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
             for (int ob = 0; ob < 4; ++ob)                    // the residual and b2 are the accumulators' initial value (1 / c2 is a power of two)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[ob][r] = fmaf(v[ob][r], A.inv_c2, sbt[FZ_SB_B2 + ob * 32 + acc_row(r, lane)]);
+#if FZ_BIASPRE
+            f32x16 d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = sbt[FZ_SB_B1 + acc_row(r, lane)];
+#endif
             // one hidden block; XC >= 0: the stage also requests chunk XC of the next tile's x, one dword behind each MFMA group of its
             // first GEMM (the transition has no memory traffic of its own; a burst at a stage's end would not be overlapped)
             auto t_stage = [&](int hb, auto xc_tag) {
                 constexpr int XC = decltype(xc_tag)::value;
-                if (HAS_P || hb + 1 < n_hb) issue(4 + hb + 1, (hb + 1) & 1);     // (hb = n_hb - 1: the first projection stage ...
+                if ((FZ_KO & 8) && hb + 1 < n_hb) { }
+                else if (HAS_P || hb + 1 < n_hb) issue(4 + hb + 1, (hb + 1) & 1);     // (hb = n_hb - 1: the first projection stage ...
                 else if (more) issue(0, 0);                                      //  ... or, in the chain without projections, the next tile's first stage)
                 const unsigned char* stage = smb + (hb & 1) * HX_STAGE_BYTES;
+#if !FZ_BIASPRE
                 f32x16 d;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) d[r] = sbt[FZ_SB_B1 + hb * 32 + acc_row(r, lane)];
+#endif
                 {
                     h8 wh = hx_frag(stage, 0, 0, lane), wl = hx_frag(stage, 0, 1, lane);
 #pragma unroll
                     for (int kc = 0; kc < 8; ++kc) {
-                        const h8 nh = hx_frag(stage, min(kc + 1, 7), 0, lane), nl = hx_frag(stage, min(kc + 1, 7), 1, lane);
+                        const h8 nh = (FZ_KO & 2) ? wh : hx_frag(stage, min(kc + 1, 7), 0, lane), nl = (FZ_KO & 2) ? wl : hx_frag(stage, min(kc + 1, 7), 1, lane);
                         PIPE_FENCE();
                         MFH3(wh, wl, zh[kc], zl[kc], d);
                         PIPE_FENCE();
@@ -413,6 +464,8 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
                     }
                 }
                 h8 ah[2], al[2];
+                if (FZ_KO & 1) { ah[0] = zh[0]; al[0] = zl[0]; ah[1] = zh[1]; al[1] = zl[1]; }
+                else
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     float x[8];
@@ -424,19 +477,25 @@ __global__ __launch_bounds__(512, 1) void k_pair_fused(const FusedArgs A) {
                     h8 bh = hx_frag(stage, 8, 0, lane), bl = hx_frag(stage, 8, 1, lane);
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        const h8 nh = hx_frag(stage, 8 + min(u + 1, 7), 0, lane), nl = hx_frag(stage, 8 + min(u + 1, 7), 1, lane);
+                        const h8 nh = (FZ_KO & 2) ? bh : hx_frag(stage, 8 + min(u + 1, 7), 0, lane), nl = (FZ_KO & 2) ? bl : hx_frag(stage, 8 + min(u + 1, 7), 1, lane);
                         PIPE_FENCE();
                         MFH3(bh, bl, ah[u >> 2], al[u >> 2], v[u & 3]);
                         PIPE_FENCE();
                         bh = nh; bl = nl;
+#if FZ_BIASPRE
+                        if (u == 1) {       // d is dead since the split: the next hidden block's biases (block n_hb reads the b2 slots: unused)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) d[r] = sbt[FZ_SB_B1 + (hb + 1) * 32 + acc_row(r, lane)];
+                        }
+#endif
                     }
                 }
                 if (FZ_XPRE && XC >= 0 && more) {
                     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // everything older than this stage's 8 x loads: the next stage's weights
                     __builtin_amdgcn_sched_barrier(0);
-                } else
+                } else if (!((FZ_KO & 4) && hb + 1 < n_hb))
                     hx_stage_landed();
-                hx_stage_barrier();
+                if (!((FZ_KO & 4) && hb + 1 < n_hb)) hx_stage_barrier();
             };
             const int n_plain = (FZ_XPRE && n_hb >= 4) ? n_hb - 4 : n_hb;
 #pragma unroll 1

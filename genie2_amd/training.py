@@ -93,7 +93,7 @@ class GenieTrainer:
             self._event.record(torch.cuda.current_stream(self.device))
             assert self._event.cuda_event != 0
             self._tail_done = torch.cuda.Event(enable_timing=True)
-        self._tail_work = None
+        self._tail_pending = False
         self.last = None
         self.logged = {}
 
@@ -102,8 +102,9 @@ class GenieTrainer:
         return _world()
 
     def _all_reduce(self, t):
-        """sum over ranks, asynchronous on the current stream (RCCL over xGMI on GPUs)"""
-        return td.all_reduce(t, async_op=True)
+        """sum over ranks, ordered behind the work already on the current stream (RCCL over xGMI on GPUs: the call returns once the
+        collective is enqueued, the current stream then waits for it; gloo on the CPU: blocking)"""
+        td.all_reduce(t)
 
     # ------------------------------------------------------------------ genie.py:60-120
     def training_step(self, batch, batch_idx=0):
@@ -121,8 +122,9 @@ class GenieTrainer:
         if overlap:     # tail bucket: reduce the structure_net gradients while the pair stack's backward pass is still running
             self._side.wait_event(self._event)
             with torch.cuda.stream(self._side):
-                self._tail_work = self._all_reduce(self.g[self.struct_offset:])
+                self._all_reduce(self.g[self.struct_offset:])
                 self._tail_done.record(self._side)
+            self._tail_pending = True
         self.last = out
         self._features = f
         return out['weighted_loss']
@@ -152,15 +154,12 @@ class GenieTrainer:
     def sync_gradients(self):
         """mean over ranks, as DistributedDataParallel does"""
         world = self._world()
-        if self._tail_work is not None:
-            head = self._all_reduce(self.g[:self.struct_offset])
-            _wait(self._tail_work)
-            _wait(head)
-            self._tail_work = None
+        if self._tail_pending:          # the tail bucket is already being reduced on the side stream: the head follows on this one
+            self._all_reduce(self.g[:self.struct_offset])
             torch.cuda.current_stream(self.device).wait_stream(self._side)
+            self._tail_pending = False
         elif world > 1:
-            _wait(self._all_reduce(self.g[self.struct_offset:]))
-            _wait(self._all_reduce(self.g[:self.struct_offset]))
+            self._all_reduce(self.g)
         if world > 1:
             self.g.mul_(1.0 / world)
 
@@ -242,8 +241,3 @@ def _numel(shape):
     for s in shape:
         n *= s
     return n
-
-
-def _wait(work):
-    if work is not None:
-        work.wait()
