@@ -40,16 +40,16 @@
 #define FZ_SAFE 0
 #endif
 #ifndef FZ_ASYM
-#define FZ_ASYM 0          // 1: a stage's LDS-DMA pieces are all issued by waves 4..7
+#define FZ_ASYM 1          // 1: a stage's LDS-DMA pieces are all issued by waves 4..7 (their SIMD partners start the stage's MFMAs at once); 0: four pieces per wave.  +0.5 % on the step
 #endif
 #ifndef FZ_BIASPRE
-#define FZ_BIASPRE 0       // 1: a transition stage's initial accumulators (b1 block) are fetched under the previous stage's second GEMM
+#define FZ_BIASPRE 1       // 1: a transition stage's initial accumulators (b1 block) are fetched under the previous stage's second GEMM (their registers are dead there): removes the kernels' last spills
 #endif
 #ifndef FZ_KO
 #define FZ_KO 0            // developer knock-outs of the transition stage (timing only, results wrong): 1 no ReLU / split, 2 no fragment re-reads, 4 no barrier / wait, 8 no weight DMA
 #endif
 #ifndef FZ_ZEARLY
-#define FZ_ZEARLY 0        // 1: the first channel half of z is requested at the tile's start (behind the x loads), not inside the first stage
+#define FZ_ZEARLY 0        // 1: the first channel half of z is requested at the tile's start (behind the x loads), not inside the first stage.  Measured: no gain -- the x loads take as much longer as the first stage gets shorter (the tile's bytes, not their latency, set both)
 #endif
 #define FZ_FULL_WAIT(bit) do { if (FZ_SAFE & (bit)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); else asm volatile("" ::: "memory"); } while (0)
 
