@@ -146,6 +146,18 @@ struct Run {
         p.asum = b_off >= 0 ? G + b_off : nullptr;      // db: the column sums of dY, taken while the GEMM streams it
         gemm(p);
     }
+    // dW[O][K] += dY^T (xhat gamma + beta) without forming xhat gamma + beta:  gamma[k] (dY^T xhat)[o][k]  +  beta[k] db[o]
+    // (db = the bias gradient the same GEMM accumulates; each Linear of the pair stack owns its bias, so db is final when the GEMM is)
+    void lin_bwd_w_ln(const float* dY, long long R, int O, const float* Xhat, int K, size_t w, size_t b_off, size_t g_off, size_t beta_off) {
+        if (!G) return;
+        GemmP p{dY, Xhat, G + w, nullptr, O, K, (int)R, 1, O, K, 1, K, 1, 1, 1, 0, 0, 0, 0, 0, 0, gemm_splits(O, K, R, 1), 1.0f, 2};
+        p.asum = G + b_off;
+        p.colscale = W + g_off;
+        gemm(p);
+        if (dry) return;
+        ProfScope ps_(h, st, KC_TR_EW);
+        launch_rank1_add(st, G + w, W + beta_off, G + b_off, O, K);
+    }
     void ln_fwd(const float* x, size_t g, size_t b, float* y, float* xhat, float* rstd, long long R, int C) {
         if (dry) return;
         ProfScope ps_(h, st, KC_TR_LN);
@@ -219,16 +231,26 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         T.off = mark;
     }
     std::vector<PairSave> ps(L);
+    // ch == 128: the gate / LayerNorm passes next to the contraction are fused with its layout changes (train_layout_kernels.hip) and the
+    // projections ap, bp are temporaries (the backward pass works from a, b themselves)
+    const bool cmf = train_cm_fusable(ch);
     auto tri_fwd = [&](const TriOff& t, TriSave& s, bool outgoing, uint32_t tag) {
-        s.xhat = K.f(P * cp); s.rstd = K.f(P); s.ap = K.f(P * ch); s.ag = K.f(P * ch); s.bp = K.f(P * ch); s.bg = K.f(P * ch);
+        s.xhat = K.f(P * cp); s.rstd = K.f(P); s.ag = K.f(P * ch); s.bg = K.f(P * ch);
+        if (!cmf) { s.ap = K.f(P * ch); s.bp = K.f(P * ch); }
         s.acm = K.f(P * ch); s.bcm = K.f(P * ch); s.xhat_o = K.f(P * ch); s.rstd_o = K.f(P); s.u = K.f(P * cp); s.g = K.f(P * cp);
         size_t mark = T.off;
         float* zn = T.f(P * cp);
+        if (cmf) { s.ap = T.f(P * ch); s.bp = T.f(P * ch); }
         r.ln_fwd(z, t.lni_g, t.lni_b, zn, s.xhat, s.rstd, P, cp);
         r.lin_fwd(zn, cp, P, cp, t.ap_w, t.ap_b, ch, s.ap); r.lin_fwd(zn, cp, P, cp, t.ag_w, t.ag_b, ch, s.ag);
         r.lin_fwd(zn, cp, P, cp, t.bp_w, t.bp_b, ch, s.bp); r.lin_fwd(zn, cp, P, cp, t.bg_w, t.bg_b, ch, s.bg);
-        float* arm = T.f(P * ch); float* brm = T.f(P * ch);
-        {
+        float *xcm, *xn;
+        if (cmf) {
+            if (!dry) { ProfScope ps_(h, st, KC_TR_TRANSPOSE); launch_gate_to_cm(st, s.ap, s.ag, s.bp, s.bg, rm, s.acm, s.bcm, B, N, ch); }
+            xcm = T.f(P * ch);
+            xn = s.ap;          // (dead from here on)
+        } else {
+            float* arm = T.f(P * ch); float* brm = T.f(P * ch);
             const float *ap = s.ap, *ag = s.ag, *bp = s.bp, *bg = s.bg;
             r.ew(P * ch, [=] __device__(long long e) {
                 const long long row = e / ch; const int j = (int)(row % N); const long long bi = row / N; const long long b = bi / N;
@@ -236,9 +258,9 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
                 arm[e] = ap[e] * m / (1.0f + expf(-ag[e]));
                 brm[e] = bp[e] * m / (1.0f + expf(-bg[e]));
             });
+            r.transpose(arm, s.acm, B, N * N, ch, true); r.transpose(brm, s.bcm, B, N * N, ch, true);
+            xcm = arm; xn = arm;
         }
-        r.transpose(arm, s.acm, B, N * N, ch, true); r.transpose(brm, s.bcm, B, N * N, ch, true);
-        float* xcm = arm;       // reuse
         {
             GemmP g{s.acm, s.bcm, xcm, nullptr, N, N, N, 0, 0, 0, 0, N, 1, B * ch, ch, (long long)ch * N * N, (long long)N * N,
                     (long long)ch * N * N, (long long)N * N, (long long)ch * N * N, (long long)N * N, 1, 1.0f, 0};
@@ -246,10 +268,13 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
             else { g.am = 1; g.ak = N; g.bk = N; g.bn = 1; }               // x[i][j] = sum_k a[k][i] b[k][j]
             r.gemm(g);
         }
-        float* xrm = brm;
-        r.transpose(xcm, xrm, B, N * N, ch, false);
-        float* xn = arm;
-        r.ln_fwd(xrm, t.lno_g, t.lno_b, xn, s.xhat_o, s.rstd_o, P, ch);
+        if (cmf) {
+            if (!dry) { ProfScope ps_(h, st, KC_TR_LN); launch_ln_from_cm(st, xcm, Wd + t.lno_g, Wd + t.lno_b, xn, s.xhat_o, s.rstd_o, B, N * N, ch); }
+        } else {
+            float* xrm = T.f(P * ch);
+            r.transpose(xcm, xrm, B, N * N, ch, false);
+            r.ln_fwd(xrm, t.lno_g, t.lno_b, xn, s.xhat_o, s.rstd_o, P, ch);
+        }
         r.lin_fwd(xn, ch, P, ch, t.z_w, t.z_b, cp, s.u);
         r.lin_fwd(zn, cp, P, cp, t.g_w, t.g_b, cp, s.g);
         {
@@ -443,16 +468,18 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
                 dgl[e] = dout * u[e] * g[e] * (1.0f - g[e]);
             });
         }
-        float* xn = T.f(P * ch);
-        { const float* xh = sv.xhat_o; const float* gg = Wd + t.lno_g; const float* bb = Wd + t.lno_b;
-          r.ew(P * ch, [=] __device__(long long e) { const int c = (int)(e % ch); xn[e] = xh[e] * gg[c] + bb[c]; }); }
-        r.lin_bwd_w(du, P, cp, xn, ch, ch, t.z_w, (long long)t.z_b);
+        // linear_z: its weight gradient against xhat_o (gamma as a column scale, beta through the bias gradient)
+        r.lin_bwd_w_ln(du, P, cp, sv.xhat_o, ch, t.z_w, t.z_b, t.lno_g, t.lno_b);
         float* dxn = T.f(P * ch);
         r.lin_bwd_x(du, P, cp, t.z_w, ch, dxn, ch, false);
-        float* dxrm = xn;
-        r.ln_bwd(dxn, sv.xhat_o, sv.rstd_o, t.lno_g, t.lno_b, dxrm, P, ch, false);
-        float* dxcm = dxn;
-        r.transpose(dxrm, dxcm, B, N * N, ch, true);
+        float* dxcm = T.f(P * ch);
+        if (cmf) {
+            if (!dry) { ProfScope ps_(h, st, KC_TR_LN); launch_ln_bwd_to_cm(st, dxn, sv.xhat_o, sv.rstd_o, Wd + t.lno_g, dxcm, B, N * N, ch, Gd ? Gd + t.lno_g : nullptr, Gd ? Gd + t.lno_b : nullptr); }
+        } else {
+            float* dxrm = T.f(P * ch);
+            r.ln_bwd(dxn, sv.xhat_o, sv.rstd_o, t.lno_g, t.lno_b, dxrm, P, ch, false);
+            r.transpose(dxrm, dxcm, B, N * N, ch, true);
+        }
         float* dacm = T.f(P * ch); float* dbcm = T.f(P * ch);
         {
             const long long bs1 = (long long)ch * N * N, bs2 = (long long)N * N;
@@ -467,10 +494,14 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
             }
             r.gemm(ga); r.gemm(gb);
         }
-        float* darm = xn; float* dbrm = dxn;
-        r.transpose(dacm, darm, B, N * N, ch, false); r.transpose(dbcm, dbrm, B, N * N, ch, false);
-        float* dap = dacm; float* dag = dbcm; float* dbp = darm; float* dbg = dbrm;      // in place where the shapes allow
-        {
+        float *dap, *dag, *dbp, *dbg;
+        if (cmf) {              // a = ap m s, so  d ap = da m s  and  d ag = da a (1 - s): the projections themselves are not needed
+            dap = dxn; dag = dxcm; dbp = T.f(P * ch); dbg = T.f(P * ch);
+            if (!dry) { ProfScope ps_(h, st, KC_TR_TRANSPOSE); launch_gate_bwd_from_cm(st, dacm, dbcm, sv.acm, sv.bcm, sv.ag, sv.bg, rm, dap, dag, dbp, dbg, B, N, ch); }
+        } else {
+            float* darm = dxn; float* dbrm = T.f(P * ch);
+            r.transpose(dacm, darm, B, N * N, ch, false); r.transpose(dbcm, dbrm, B, N * N, ch, false);
+            dap = dacm; dag = dbcm; dbp = darm; dbg = dbrm;      // in place where the shapes allow
             const float *ap = sv.ap, *ag = sv.ag, *bp = sv.bp, *bg = sv.bg;
             r.ew(P * ch, [=] __device__(long long e) {
                 const long long row = e / ch; const int j = (int)(row % N); const long long bi = row / N; const long long b = bi / N;
@@ -481,15 +512,13 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
                 dbp[e] = db * sb; dbg[e] = db * bp[e] * sb * (1.0f - sb);
             });
         }
-        float* zn = T.f(P * cp);
-        { const float* xh = sv.xhat; const float* gg = Wd + t.lni_g; const float* bb = Wd + t.lni_b;
-          r.ew(P * cp, [=] __device__(long long e) { const int c = (int)(e % cp); zn[e] = xh[e] * gg[c] + bb[c]; }); }
+        // the five Linears on LN_in(z): weight gradients against xhat, input gradients summed into dzn
         float* dzn = T.f(P * cp);
-        r.lin_bwd_w(dap, P, ch, zn, cp, cp, t.ap_w, (long long)t.ap_b); r.lin_bwd_x(dap, P, ch, t.ap_w, cp, dzn, cp, false);
-        r.lin_bwd_w(dag, P, ch, zn, cp, cp, t.ag_w, (long long)t.ag_b); r.lin_bwd_x(dag, P, ch, t.ag_w, cp, dzn, cp, true);
-        r.lin_bwd_w(dbp, P, ch, zn, cp, cp, t.bp_w, (long long)t.bp_b); r.lin_bwd_x(dbp, P, ch, t.bp_w, cp, dzn, cp, true);
-        r.lin_bwd_w(dbg, P, ch, zn, cp, cp, t.bg_w, (long long)t.bg_b); r.lin_bwd_x(dbg, P, ch, t.bg_w, cp, dzn, cp, true);
-        r.lin_bwd_w(dgl, P, cp, zn, cp, cp, t.g_w, (long long)t.g_b); r.lin_bwd_x(dgl, P, cp, t.g_w, cp, dzn, cp, true);
+        r.lin_bwd_w_ln(dap, P, ch, sv.xhat, cp, t.ap_w, t.ap_b, t.lni_g, t.lni_b); r.lin_bwd_x(dap, P, ch, t.ap_w, cp, dzn, cp, false);
+        r.lin_bwd_w_ln(dag, P, ch, sv.xhat, cp, t.ag_w, t.ag_b, t.lni_g, t.lni_b); r.lin_bwd_x(dag, P, ch, t.ag_w, cp, dzn, cp, true);
+        r.lin_bwd_w_ln(dbp, P, ch, sv.xhat, cp, t.bp_w, t.bp_b, t.lni_g, t.lni_b); r.lin_bwd_x(dbp, P, ch, t.bp_w, cp, dzn, cp, true);
+        r.lin_bwd_w_ln(dbg, P, ch, sv.xhat, cp, t.bg_w, t.bg_b, t.lni_g, t.lni_b); r.lin_bwd_x(dbg, P, ch, t.bg_w, cp, dzn, cp, true);
+        r.lin_bwd_w_ln(dgl, P, cp, sv.xhat, cp, t.g_w, t.g_b, t.lni_g, t.lni_b); r.lin_bwd_x(dgl, P, cp, t.g_w, cp, dzn, cp, true);
         r.ln_bwd(dzn, sv.xhat, sv.rstd, t.lni_g, t.lni_b, dP, P, cp, true);
         T.off = mark;
     };
@@ -508,10 +537,7 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         r.lin_bwd_w(dot, P, cp, sv.h, nh, nh, o.w2, (long long)o.b2);
         float* dh = T.f(P * nh);
         r.lin_bwd_x(dot, P, cp, o.w2, nh, dh, nh, false, sv.h);          // through the ReLU
-        float* zn = T.f(P * cp);
-        { const float* xh = sv.xhat; const float* gg = Wd + o.ln_g; const float* bb = Wd + o.ln_b;
-          r.ew(P * cp, [=] __device__(long long e) { const int c = (int)(e % cp); zn[e] = xh[e] * gg[c] + bb[c]; }); }
-        r.lin_bwd_w(dh, P, nh, zn, cp, cp, o.w1, (long long)o.b1);
+        r.lin_bwd_w_ln(dh, P, nh, sv.xhat, cp, o.w1, o.b1, o.ln_g, o.ln_b);
         float* dzn = dot;
         r.lin_bwd_x(dh, P, nh, o.w1, cp, dzn, cp, false);
         r.ln_bwd(dzn, sv.xhat, sv.rstd, o.ln_g, o.ln_b, dP, P, cp, true);

@@ -16,6 +16,8 @@ struct GemmP {
     const float* gate;  // mode 0: store v where gate > 0, else 0; gate is laid out like C   (ReLU backward on the dX GEMM)
     float* asum;      // optional (batch 1, A dense [K][M] with am == 1): asum[m] += sum_k A[m][k] -- a Linear's bias gradient rides on its
                       // weight-gradient GEMM, which streams dY anyway
+    const float* colscale;   // optional: the product's column n is scaled by colscale[n] before bias / accumulation -- a weight gradient
+                             // taken against LayerNorm's xhat instead of xhat * gamma + beta (the beta part is launch_rank1_add's)
 };
 void launch_gemm(hipStream_t st, const GemmP& p, int terms);
 int gemm_splits(long long M, long long N, long long K, long long batch);
@@ -25,6 +27,21 @@ void launch_ln_bwd(hipStream_t st, const float* dy, const float* xhat, const flo
                    float* dgamma, float* dbeta);
 void launch_colsum(hipStream_t st, const float* a, const float* w, long long R, int C, float* out_b, float* out_g);
 void launch_transpose(hipStream_t st, const float* in, float* out, int B, int R, int C, bool to_cm);
+// Fused layout changes around the triangle multiplication's contraction (row-major [B][N N][C] <-> channel-major [B][C][N N]); C = 128 k:
+//   gate_to_cm:       a = ap m sigmoid(ag), b = bp m sigmoid(bg)  (row-major in) -> acm, bcm (channel-major out)
+//   ln_from_cm:       x (channel-major) -> LayerNorm over channels -> y = xhat g + b, xhat (row-major), rstd
+//   ln_bwd_to_cm:     LayerNorm backward of row-major dy -> dx written channel-major; gamma / beta gradients
+//   gate_bwd_from_cm: da, db, a, b (channel-major) + ag, bg (row-major) -> d ap, d ag, d bp, d bg (row-major)
+bool train_cm_fusable(int C);
+void launch_gate_to_cm(hipStream_t st, const float* ap, const float* ag, const float* bp, const float* bg, const float* rmask, float* acm, float* bcm,
+                       int B, int N, int C);
+void launch_ln_from_cm(hipStream_t st, const float* xcm, const float* g, const float* b, float* y, float* xhat, float* rstd, int B, int R, int C);
+void launch_ln_bwd_to_cm(hipStream_t st, const float* dy, const float* xhat, const float* rstd, const float* g, float* dxcm, int B, int R, int C,
+                         float* dgamma, float* dbeta);
+void launch_gate_bwd_from_cm(hipStream_t st, const float* dacm, const float* dbcm, const float* acm, const float* bcm, const float* ag, const float* bg,
+                             const float* rmask, float* dap, float* dag, float* dbp, float* dbg, int B, int N, int C);
+// dW[o][c] += beta[c] db[o]   (the beta part of a weight gradient taken against xhat, see GemmP::colscale)
+void launch_rank1_add(hipStream_t st, float* dW, const float* beta, const float* db, int O, int C);
 void launch_pair_features(hipStream_t st, const float* trans, const float* rots, const int8_t* codes, const float* rmask, const uint8_t* fstm,
                           const uint8_t* fsm, const float* mpos, const int32_t* ridx, const int32_t* cidx, float* F, int B, int N, int nbin,
                           float dmin, float dstep, int relk);

@@ -212,12 +212,13 @@ __global__ __launch_bounds__(256, GM_WPS) void k_gemm(const GemmP p, const int v
                 const int col = cur.n0 + wn * 32 + (lane & 31);
                 if (col < p.N && !((GM_EXP & 4) && acc[0] != 12345.f)) {
                     const float bv = (p.bias && cur.sp == 0) ? p.bias[col] : 0.f;
+                    const float al = p.colscale ? p.alpha * p.colscale[col] : p.alpha;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = cur.m0 + wm * 32 + acc_row(r, lane);
                         if (row >= p.M) continue;
                         float* d = cur.C + (long long)row * p.cm + (long long)col * p.cn;
-                        float v = acc[r] * p.alpha + bv;
+                        float v = acc[r] * al + bv;
                         if (p.mode == 0) {
                             if (p.relu) v = fmaxf(v, 0.f);
                             if (p.gate && !(p.gate[d - p.C] > 0.f)) v = 0.f;
@@ -332,23 +333,24 @@ __global__ __launch_bounds__(256, GM_WPS) void k_gemm_fast(const GemmP p) {
     }
     const int col = n0 + wn * 32 + (lane & 31);
     const float bv = (p.bias && sp == 0) ? p.bias[col] : 0.f;
+    const float al = p.colscale ? p.alpha * p.colscale[col] : p.alpha;
     float* d0 = p.C + z1 * p.c1 + z2 * p.c2 + (long long)(m0 + wm * 32 + 4 * (lane >> 5)) * p.cm + (long long)col * p.cn;
     if (p.mode == 0) {
         const float* g0 = p.gate ? p.gate + (d0 - p.C) : nullptr;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const long long o = (long long)((r & 3) + 8 * (r >> 2)) * p.cm;
-            float v = acc[r] * p.alpha + bv;
+            float v = acc[r] * al + bv;
             if (p.relu) v = fmaxf(v, 0.f);
             if (g0 && !(g0[o] > 0.f)) v = 0.f;
             d0[o] = v;
         }
     } else if (p.mode == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) d0[(long long)((r & 3) + 8 * (r >> 2)) * p.cm] += acc[r] * p.alpha + bv;
+        for (int r = 0; r < 16; ++r) d0[(long long)((r & 3) + 8 * (r >> 2)) * p.cm] += acc[r] * al + bv;
     } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) atomicAdd(d0 + (long long)((r & 3) + 8 * (r >> 2)) * p.cm, acc[r] * p.alpha + bv);
+        for (int r = 0; r < 16; ++r) atomicAdd(d0 + (long long)((r & 3) + 8 * (r >> 2)) * p.cm, acc[r] * al + bv);
     }
 }
 // ---- the same for M and N multiples of 128: a 128 x 128 tile per 512-thread work-group, eight waves of 32 x 64 (two accumulators).
@@ -451,23 +453,24 @@ __global__ __launch_bounds__(512, 4) void k_gemm_big(const GemmP p) {
         const f32x16& acc = half ? acc1 : acc0;
         const int col = n0 + wn * 64 + 32 * half + (lane & 31);
         const float bv = (p.bias && sp == 0) ? p.bias[col] : 0.f;
+        const float al = p.colscale ? p.alpha * p.colscale[col] : p.alpha;
         float* d0 = dbase + (long long)col * p.cn;
         if (p.mode == 0) {
             const float* g0 = p.gate ? p.gate + (d0 - p.C) : nullptr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long long o = (long long)((r & 3) + 8 * (r >> 2)) * p.cm;
-                float v = acc[r] * p.alpha + bv;
+                float v = acc[r] * al + bv;
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (g0 && !(g0[o] > 0.f)) v = 0.f;
                 d0[o] = v;
             }
         } else if (p.mode == 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d0[(long long)((r & 3) + 8 * (r >> 2)) * p.cm] += acc[r] * p.alpha + bv;
+            for (int r = 0; r < 16; ++r) d0[(long long)((r & 3) + 8 * (r >> 2)) * p.cm] += acc[r] * al + bv;
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) atomicAdd(d0 + (long long)((r & 3) + 8 * (r >> 2)) * p.cm, acc[r] * p.alpha + bv);
+            for (int r = 0; r < 16; ++r) atomicAdd(d0 + (long long)((r & 3) + 8 * (r >> 2)) * p.cm, acc[r] * al + bv);
         }
     }
 }
