@@ -527,8 +527,11 @@ def test_rccl_one_rank_bucketed_all_reduce_on_the_device(tmp_path):
     r = json.load(open(out))
     print(r)
     assert r['event_handle_nonzero']
-    assert max(r['grad_rel_overlap']) <= 1e-5
-    assert max(r['grad_rel_sim2_tail']) <= 1e-5 and max(r['grad_rel_sim2_head']) <= 1e-5       # 0.5 if the tail was reduced too early
+    # step 0: the same weights, so only the float-atomic summation order differs; step 1 starts from weights that already differ by
+    # Adam's amplification of that noise.  A tail bucket reduced before its gradients are final would be off by 0.5 .. 1.
+    assert r['grad_rel_overlap'][0] <= 1e-5 and max(r['grad_rel_overlap']) <= 1e-3
+    assert r['grad_rel_sim2_tail'][0] <= 1e-5 and r['grad_rel_sim2_head'][0] <= 1e-5
+    assert max(r['grad_rel_sim2_tail']) <= 1e-3 and max(r['grad_rel_sim2_head']) <= 1e-3
     assert r['w_maxdiff_overlap'] <= 2.5e-3 and r['w_meandiff_overlap'] <= 1e-6
     assert r['w_maxdiff_sim2'] <= 2.5e-3 and r['w_meandiff_sim2'] <= 1e-6
     for t in (r['timing_overlap'], r['timing_sim2']):

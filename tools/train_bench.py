@@ -33,3 +33,9 @@ for it in range(3):
     adam_step(w, g, m, v, 1e-4, it + 1)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f'N={N} B={B} fast_math={fast} step {it}: {dt * 1e3:.1f} ms, loss {float(out["weighted_loss"]):.4f}, workspace {eng.lib.genie_train_workspace_bytes(eng._h) / 2**30:.2f} GiB', flush=True)
+eng.profile(True)
+out = eng.train_forward_backward(w, trans, rots, s, z, 1.0, grads=g, seed=9, fast_math=fast)
+torch.cuda.synchronize()
+eng.profile(False)
+prof = {k: v for k, v in eng.profile_read().items() if k.startswith('train_')}
+print('per class (ms, launches):', {k: (round(ms, 2), n) for k, (ms, n) in prof.items()}, 'gemm TFLOP', eng.lib.genie_train_gemm_flop(eng._h) / 1e12, flush=True)
