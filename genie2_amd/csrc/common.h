@@ -268,6 +268,9 @@ struct genie_ctx {
     ProfRec* prof_recs; int prof_n, prof_cap;
     double prof_ms[KC_COUNT]; int64_t prof_cnt[KC_COUNT];
     double train_gemm_flop;       // algorithmic FLOP (2 M N K per product) of the GEMMs the last training call launched
+
+    // the structure net's second stream (genie_api.hip: the two halves of a batch run their layers side by side)
+    hipStream_t st2; hipEvent_t ev_fork, ev_join;
 };
 
 // launchers (each enqueues on `st`, no sync)
@@ -284,13 +287,15 @@ void launch_trimul(genie_ctx* h, hipStream_t st, const TriMulW& w, bool outgoing
 void launch_pair_transition(genie_ctx* h, hipStream_t st, const PairLayerW& w);
 bool launch_pair_stack_fused(genie_ctx* h, hipStream_t st, float* tap_trimul_out0, float* tap_layer0);   // false: not applicable, use the launches above
 void launch_ipa_bias(genie_ctx* h, hipStream_t st);
-void launch_ipa_prep(genie_ctx* h, hipStream_t st);
-void launch_ipa_attn(genie_ctx* h, hipStream_t st, int layer, const float* head_w);
+void launch_ipa_prep(genie_ctx* h, hipStream_t st, int b0 = 0, int nb = -1);       // batch entries b0 .. b0 + nb - 1 (nb < 0: all)
+void launch_ipa_attn(genie_ctx* h, hipStream_t st, int layer, const float* head_w, int b0 = 0, int nb = -1);
+bool ipa_attn_splits(const genie_ctx* h);         // the attention kernel in use takes a batch range
 void launch_q_sample(genie_ctx* h, hipStream_t st, const float* x0, const float* z, const float* c0, const float* c1, float* trans_out);
 void launch_training_loss(genie_ctx* h, hipStream_t st, const float* zp, const float* z, float w, float* losses, float* grad);
 void launch_adam(hipStream_t st, size_t n, float* p, const float* g, float* m, float* v, double lr, double b1, double b2, double eps, int step);
 void launch_any_nonzero(genie_ctx* h, hipStream_t st, const uint8_t* x, size_t n, unsigned* flag);
-bool launch_struct_tail(genie_ctx* h, hipStream_t st, const StructLayerW& S, const float* trans_in, float* z_out);
+bool launch_struct_tail(genie_ctx* h, hipStream_t st, const StructLayerW& S, const float* trans_in, float* z_out, int b0 = 0, int nb = -1);
+bool struct_tail_fused(const genie_ctx* h, const StructLayerW& S);
 void launch_bb_update(genie_ctx* h, hipStream_t st, const StructLayerW& w, const float* trans_in,
                       float* z_out);
 void launch_frenet(genie_ctx* h, hipStream_t st, int mode, int step, float scale, float* trans,

@@ -314,8 +314,8 @@ __global__ __launch_bounds__(256) void k_layernorm_rows(const float* __restrict_
 // ---------------------------------------------------------------------------
 __global__ void k_ipa_prep(const float* __restrict__ proj, int ldp, const float* __restrict__ rots, const float* __restrict__ trans,
                            float* __restrict__ kT, float* __restrict__ v, float* __restrict__ qp, float* __restrict__ kpT,
-                           float* __restrict__ vp, int N, int H, int C, int Pq, int Pv) {
-    const int row = blockIdx.x, b = row / N, n = row % N;
+                           float* __restrict__ vp, int N, int H, int C, int Pq, int Pv, int row0) {
+    const int row = row0 + blockIdx.x, b = row / N, n = row % N;
     const float* pr = proj + (size_t)row * ldp;
     const float* R = rots + (size_t)row * 9;
     const float* t = trans + (size_t)row * 3;
@@ -1154,7 +1154,7 @@ __global__ __launch_bounds__(MF ? 128 * Q : 512, MF ? 4 : 1) void k_ipa_attn_q(c
                                                     const float* __restrict__ rots, const float* __restrict__ trans,
                                                     const float* __restrict__ rmask, const float* __restrict__ head_w,
                                                     float* __restrict__ cat, int B, int N, int layer, int rev,
-                                                    const unsigned* __restrict__ pmax, unsigned long long* ts) {
+                                                    const unsigned* __restrict__ pmax, unsigned long long* ts, int b0) {
     // NT threads: 512 (Q = 4), or 1024 with the matrix-pipe o_pair and Q = 8 -- two waves per query there, and every K / V value
     // fetched from L2 then serves eight queries: the logits and o / o_pt phases are bound by the CU's L2 read path (~35 B/clk)
     constexpr int NT = MF ? 128 * Q : 512;
@@ -1174,7 +1174,7 @@ __global__ __launch_bounds__(MF ? 128 * Q : 512, MF ? 4 : 1) void k_ipa_attn_q(c
     // `rev` alternates per layer (starting opposite to the pair-bias kernel's pass): p (268 MB at N = 256, batch 8) is re-read
     // by every layer, and a fixed direction would evict from the 256-MiB Infinity Cache exactly what the next reader needs first
     const int bid = rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
-    const int b = bid / groups, i0 = (bid % groups) * Q;
+    const int b = b0 + bid / groups, i0 = (bid % groups) * Q;       // the grid covers batch entries b0 .. (B stays the tensor's batch count)
     const int nq = min(Q, N - i0);
     int ts_n = 0;                                  // developer aid (GENIE_SR_TS=1): s_memtime at the phase boundaries of work-group 0
     auto stamp = [&]() { if (ts && blockIdx.x == 0 && tid == 0) ts[ts_n++] = __builtin_amdgcn_s_memtime(); };
@@ -1582,12 +1582,13 @@ void launch_layernorm_rows(genie_ctx* h, hipStream_t st, const float* in, float*
     hipLaunchKernelGGL(k_layernorm_rows, dim3((M + 3) / 4), dim3(256), 0, st, in, out, M, C, g, b);
 }
 
-void launch_ipa_prep(genie_ctx* h, hipStream_t st) {
+void launch_ipa_prep(genie_ctx* h, hipStream_t st, int b0, int nb) {
     ProfScope ps(h, st, KC_IPA_PREP);
     const genie_dims_t& d = h->d;
+    if (nb < 0) { b0 = 0; nb = h->B; }
     const int ldp = d.n_head_ipa * (3 * d.c_hidden_ipa + 3 * d.n_qk_point + 3 * (d.n_qk_point + d.n_v_point));
-    hipLaunchKernelGGL(k_ipa_prep, dim3(h->B * h->N), dim3(256), 0, st, h->proj, ldp, h->rots_w, h->trans_w, h->kT, h->v, h->qp,
-                       h->kpT, h->vp, h->N, d.n_head_ipa, d.c_hidden_ipa, d.n_qk_point, d.n_v_point);
+    hipLaunchKernelGGL(k_ipa_prep, dim3(nb * h->N), dim3(256), 0, st, h->proj, ldp, h->rots_w, h->trans_w, h->kT, h->v, h->qp,
+                       h->kpT, h->vp, h->N, d.n_head_ipa, d.c_hidden_ipa, d.n_qk_point, d.n_v_point, b0 * h->N);
 }
 
 static bool ipa_is_base(const genie_dims_t& d) {
@@ -1613,9 +1614,12 @@ size_t ipa_attn_lds(const genie_dims_t& d, int N) {
     return ((size_t)d.n_head_ipa * N + 8 * d.n_head_ipa * d.c_p + d.n_head_ipa * d.n_v_point * 3) * sizeof(float);
 }
 
-void launch_ipa_attn(genie_ctx* h, hipStream_t st, int layer, const float* head_w) {
+// the four-query kernel takes a batch range (the two halves of a batch run their structure layers on two streams)
+bool ipa_attn_splits(const genie_ctx* h) { return ipa_is_base(h->d) && ipa_use_q(h->d, h->N); }
+void launch_ipa_attn(genie_ctx* h, hipStream_t st, int layer, const float* head_w, int b0, int nb) {
     ProfScope ps(h, st, KC_IPA_ATTN);
     const genie_dims_t& d = h->d;
+    if (nb < 0 || !ipa_attn_splits(h)) { b0 = 0; nb = h->B; }
     const int ldp = d.n_head_ipa * (3 * d.c_hidden_ipa + 3 * d.n_qk_point + 3 * (d.n_qk_point + d.n_v_point));
     if (ipa_is_base(d) && !ipa_use_q(d, h->N)) {
         hipLaunchKernelGGL((k_ipa_attn_t<12, 16, 4, 8>), dim3(h->B * h->N), dim3(256), ipa_attn_t1_lds(d, h->N), st, h->proj, ldp,
@@ -1624,22 +1628,22 @@ void launch_ipa_attn(genie_ctx* h, hipStream_t st, int layer, const float* head_
         return;
     }
     if (ipa_is_base(d)) {
-        const dim3 grid(h->B * ((h->N + IPA_Q - 1) / IPA_Q));
+        const dim3 grid(nb * ((h->N + IPA_Q - 1) / IPA_Q));
         const int rev = (int)((layer ^ h->hx_launches ^ 1) & 1);
         static unsigned long long* ts = nullptr;
         if (!ts && getenv("GENIE_SR_TS")) (void)hipMalloc((void**)&ts, 64 * sizeof(unsigned long long));
         if (h->hx && ipa_use_q8(d, h->N))
-            hipLaunchKernelGGL((k_ipa_attn_q<12, 16, 4, 8, IPA_Q8, 1>), dim3(h->B * ((h->N + IPA_Q8 - 1) / IPA_Q8)), dim3(1024),
+            hipLaunchKernelGGL((k_ipa_attn_q<12, 16, 4, 8, IPA_Q8, 1>), dim3(nb * ((h->N + IPA_Q8 - 1) / IPA_Q8)), dim3(1024),
                                ipa_attn_q_lds(d, h->N, true, IPA_Q8), st, h->proj, ldp, h->kT, h->v, h->qp, h->kpT, h->vp, h->ipa_bias, h->p,
-                               h->rots_w, h->trans_w, h->rmaskf, head_w, h->cat, h->B, h->N, layer, rev, h->pmax, ts);
+                               h->rots_w, h->trans_w, h->rmaskf, head_w, h->cat, h->B, h->N, layer, rev, h->pmax, ts, b0);
         else if (h->hx)
             hipLaunchKernelGGL((k_ipa_attn_q<12, 16, 4, 8, IPA_Q, 1>), grid, dim3(512), ipa_attn_q_lds(d, h->N, true), st, h->proj, ldp,
                                h->kT, h->v, h->qp, h->kpT, h->vp, h->ipa_bias, h->p, h->rots_w, h->trans_w, h->rmaskf, head_w, h->cat,
-                               h->B, h->N, layer, rev, h->pmax, ts);
+                               h->B, h->N, layer, rev, h->pmax, ts, b0);
         else
             hipLaunchKernelGGL((k_ipa_attn_q<12, 16, 4, 8, IPA_Q, 0>), grid, dim3(512), ipa_attn_q_lds(d, h->N), st, h->proj, ldp,
                                h->kT, h->v, h->qp, h->kpT, h->vp, h->ipa_bias, h->p, h->rots_w, h->trans_w, h->rmaskf, head_w, h->cat,
-                               h->B, h->N, layer, rev, h->pmax, ts);
+                               h->B, h->N, layer, rev, h->pmax, ts, b0);
         if (ts) {
             unsigned long long v[24] = {0};
             (void)hipStreamSynchronize(st);
@@ -1672,24 +1676,30 @@ static const HxGemmW* hx_image(const genie_ctx* h, const float* Wp) {
 // IPA output projection (split-K, three slices) and the fused tail (their sum + bias + residual -> LayerNorm -> structure
 // transition -> LayerNorm -> BackboneUpdate), two launches; false = this configuration keeps the separate launches (f32
 // arithmetic, c_s != 384)
-bool launch_struct_tail(genie_ctx* h, hipStream_t st, const StructLayerW& S, const float* trans_in, float* z_out) {
+bool struct_tail_fused(const genie_ctx* h, const StructLayerW& S) {
     if (!h->hx || h->d.c_s != 384 || getenv("GENIE_NO_STRUCT_FUSE")) return false;
+    return hx_image(h, S.out_w) && hx_image(h, S.t1_w) && hx_image(h, S.t2_w) && hx_image(h, S.t3_w);
+}
+// rows of batch entries b0 .. b0 + nb - 1 (nb < 0: all)
+bool launch_struct_tail(genie_ctx* h, hipStream_t st, const StructLayerW& S, const float* trans_in, float* z_out, int b0, int nb) {
+    if (!struct_tail_fused(h, S)) return false;
     const HxGemmW *w0 = hx_image(h, S.out_w), *w1 = hx_image(h, S.t1_w), *w2 = hx_image(h, S.t2_w), *w3 = hx_image(h, S.t3_w);
-    if (!w0 || !w1 || !w2 || !w3) return false;
-    const int M = h->B * h->N, cs = h->d.c_s, ncat = h->d.n_head_ipa * (h->d.c_p + h->d.c_hidden_ipa + 4 * h->d.n_v_point);
-    const size_t zs = (size_t)M * cs;
+    if (nb < 0) { b0 = 0; nb = h->B; }
+    const int Mall = h->B * h->N, M = nb * h->N, cs = h->d.c_s, ncat = h->d.n_head_ipa * (h->d.c_p + h->d.c_hidden_ipa + 4 * h->d.n_v_point);
+    const size_t zs = (size_t)Mall * cs, r0 = (size_t)b0 * h->N;          // slice stride of the split-K partial sums; first row
     {
         ProfScope ps(h, st, KC_GEMM_ROWS);
-        hipLaunchKernelGGL(k_gemm_rows_hx, dim3((M + 31) / 32, (cs + 127) / 128, SR_KSPLIT), dim3(256), 0, st, h->cat, ncat, M, ncat,
-                           w0->img, cs, w0->inv_s, nullptr, nullptr, 0, nullptr, 0, h->spart, cs, zs);
+        hipLaunchKernelGGL(k_gemm_rows_hx, dim3((M + 31) / 32, (cs + 127) / 128, SR_KSPLIT), dim3(256), 0, st, h->cat + r0 * ncat, ncat, M, ncat,
+                           w0->img, cs, w0->inv_s, nullptr, nullptr, 0, nullptr, 0, h->spart + r0 * cs, cs, zs);
     }
     ProfScope ps(h, st, KC_STRUCT_ROWS);
     static unsigned long long* ts = nullptr;
     if (!ts && getenv("GENIE_SR_TS")) (void)hipMalloc((void**)&ts, 64 * sizeof(unsigned long long));
     const int nrb = (M + 31) / 32;                 // row work-groups; + 64 L2 prefetchers (8 per XCD) on CUs the rows leave idle
-    hipLaunchKernelGGL((k_struct_rows_hx<12>), dim3(nrb + 64), dim3(768), struct_rows_lds(), st, h->spart, SR_KSPLIT, zs, S.out_b, h->s,
+    hipLaunchKernelGGL((k_struct_rows_hx<12>), dim3(nrb + 64), dim3(768), struct_rows_lds(), st, h->spart + r0 * cs, SR_KSPLIT, zs, S.out_b, h->s + r0 * cs,
                        S.ln_ipa_g, S.ln_ipa_b, w1->img, w1->inv_s, S.t1_b, w2->img, w2->inv_s, S.t2_b, w3->img, w3->inv_s, S.t3_b,
-                       S.ln_tr_g, S.ln_tr_b, S.bb_w, S.bb_b, h->s, h->rots_w, h->trans_w, M, trans_in, z_out, 1.0f / h->d.rescale, nrb, ts);
+                       S.ln_tr_g, S.ln_tr_b, S.bb_w, S.bb_b, h->s + r0 * cs, h->rots_w + r0 * 9, h->trans_w + r0 * 3, M, trans_in ? trans_in + r0 * 3 : nullptr,
+                       z_out ? z_out + r0 * 3 : nullptr, 1.0f / h->d.rescale, nrb, ts);
     if (ts) {
         unsigned long long v[8] = {0};
         (void)hipStreamSynchronize(st);

@@ -552,3 +552,35 @@ def test_heavy_tailed_pair_weights_and_large_layernorm_gains(math):
     assert mdiff(out['p'], ref['p']) <= 1e-4 * max(1.0, float(ref['p'].abs().max()))
     assert mdiff(out['z'].cpu() * m, ref['z'] * m) <= 1e-4 * max(1.0, float(ref['z'].abs().max()))
     eng.close()
+
+
+def test_two_stream_structure_net_is_bit_identical(base_engine, monkeypatch):
+    """From 1024 rows up the structure layers of the two halves of a batch run on two streams (genie_api.hip denoise_internal: every
+    kernel of a layer takes a batch range; fork / join by events each call): z, all nine states, the first layer's attention output and
+    the frames must equal the single-stream order (GENIE_NO_STRUCT_SPLIT=1) BIT FOR BIT, here on an odd, ragged batch (5 structures,
+    halves of 2 and 3) and over consecutive reverse-loop steps (the events are reused every step)."""
+    f = O.empty_features([256, 201, 256, 180, 233])
+    g = torch.Generator().manual_seed(9)
+    B, N = f['residue_mask'].shape
+    x = torch.randn(B, N, 3, generator=g) * 6
+    base_engine.set_math('hx')
+    base_engine.bind_features(f)
+    r = base_engine.frenet(x)
+    ts = torch.randint(1, 1001, (B,), generator=g).int()
+    T = base_engine.dims['n_timestep']
+    noise = torch.randn(T, B, N, 3, generator=g)
+    taps = ('states', 's_final', 'ipa_cat0', 'rots_out', 'trans_out')
+    res = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv('GENIE_NO_STRUCT_SPLIT', '1')
+        else:
+            monkeypatch.delenv('GENIE_NO_STRUCT_SPLIT', raising=False)
+        out = base_engine.denoise(x, r, ts, None, taps=taps)
+        tr, ro, _ = base_engine.sample_loop(noise, 0.6, first_step=T, last_step=T - 5)
+        out['traj'], out['traj_rots'] = tr.clone(), ro.clone()
+        res.append(out)
+    monkeypatch.delenv('GENIE_NO_STRUCT_SPLIT', raising=False)
+    for k in res[0]:
+        assert torch.isfinite(res[0][k]).all(), k
+        assert torch.equal(res[0][k], res[1][k]), k

@@ -86,18 +86,19 @@ int main() {
     hipFuncSetAttribute(reinterpret_cast<const void*>(probe<8, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 65536);
     hipFuncSetAttribute(reinterpret_cast<const void*>(probe<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 70 * 1024);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    const int tiles = 16;
+    const int tiles = 160;          // >= 10 ms per configuration: the clock the chip settles at under each mix is part of the answer
+  for (int rep = 0; rep < 2; ++rep)
     for (int nst : {28, 12}) {
         for (int mem : {1, 0}) {
             float ms;
             // 8x1: LDS sized so that only one group fits per CU
-            probe<8, 16><<<256, 512, 131072>>>(out, src, dst, 2, nst, SB, DB, rnd, 0, mem);
+            probe<8, 16><<<256, 512, 131072>>>(out, src, dst, 40, nst, SB, DB, rnd, 0, mem);
             hipDeviceSynchronize(); hipEventRecord(a);
             probe<8, 16><<<256, 512, 131072>>>(out, src, dst, tiles, nst, SB, DB, rnd, 0, mem);
             hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b);
             printf("stages %2d mem %d  8 waves x 1 group            : %7.1f us per tile (256 pair rows) \n", nst, mem, ms * 1e3 / tiles);
             for (int delay : {0, 60000}) {
-                probe<4, 8><<<512, 256, 70 * 1024>>>(out, src, dst, 2, 2 * nst, SB, DB, rnd, delay, mem);
+                probe<4, 8><<<512, 256, 70 * 1024>>>(out, src, dst, 40, 2 * nst, SB, DB, rnd, delay, mem);
                 hipDeviceSynchronize(); hipEventRecord(a);
                 probe<4, 8><<<512, 256, 70 * 1024>>>(out, src, dst, tiles, 2 * nst, SB, DB, rnd, delay, mem);
                 hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b);

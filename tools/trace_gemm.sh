@@ -3,7 +3,7 @@
 # timeline (start offset, duration, gap to the previous kernel's end) of one structure layer
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/trace_gemm; rm -rf $OUT; mkdir -p $OUT
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --profile-steps 1 > $OUT/log.txt 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra-legs --profile-steps 1 > $OUT/log.txt 2>&1
 python3 - <<'PY'
 import csv, glob, collections
 f = glob.glob('gpurun_out/trace_gemm/**/*kernel_trace.csv', recursive=True)[0]
