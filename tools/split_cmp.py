@@ -11,7 +11,7 @@ from genie2_amd.engine import GenieEngine           # noqa: E402
 dev = torch.device('cuda', 0)
 dims = dict(pack.BASE_DIMS)
 T = dims['n_timestep']
-for (B, N) in ((8, 256), (32, 128)):
+for (B, N) in ((8, 256),):
     eng = GenieEngine(dims, pack.random_state_dict(dims, seed=0), dev)
     feats = F.convert_np_features_to_tensor(F.batchify_np_features([F.create_empty_np_features([N - (3 * i) % 7]) for i in range(B)]), dev)
     eng.bind_features(feats)
