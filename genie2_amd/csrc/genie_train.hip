@@ -139,6 +139,11 @@ struct Run {
         p.gate = relu_out;
         gemm(p);
     }
+    // dX[R][K] = dY[R][O] Wc[O][K] with the weight at a raw device pointer (a concatenation of several Linears' matrices)
+    void lin_bwd_x_ptr(const float* dY, long long R, int O, const float* Wc, int K, float* dX, long long lddx) {
+        GemmP p{dY, Wc, dX, nullptr, (int)R, K, O, O, 1, K, 1, lddx, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0f, 0};
+        gemm(p);
+    }
     // dW[O][K] += dY[R][O]^T X[R][K];  db[O] += column sums of dY
     void lin_bwd_w(const float* dY, long long R, int O, const float* X, long long ldx, int K, size_t w, long long b_off) {
         if (!G) return;                     // input-gradient only (genie_denoise_vjp)
@@ -148,9 +153,10 @@ struct Run {
     }
     // dW[O][K] += dY^T (xhat gamma + beta) without forming xhat gamma + beta:  gamma[k] (dY^T xhat)[o][k]  +  beta[k] db[o]
     // (db = the bias gradient the same GEMM accumulates; each Linear of the pair stack owns its bias, so db is final when the GEMM is)
-    void lin_bwd_w_ln(const float* dY, long long R, int O, const float* Xhat, int K, size_t w, size_t b_off, size_t g_off, size_t beta_off) {
+    // (lddy: row stride of dY -- it may be a column block of a wider matrix)
+    void lin_bwd_w_ln(const float* dY, long long R, int O, const float* Xhat, int K, size_t w, size_t b_off, size_t g_off, size_t beta_off, long long lddy = 0) {
         if (!G) return;
-        GemmP p{dY, Xhat, G + w, nullptr, O, K, (int)R, 1, O, K, 1, K, 1, 1, 1, 0, 0, 0, 0, 0, 0, gemm_splits(O, K, R, 1), 1.0f, 2};
+        GemmP p{dY, Xhat, G + w, nullptr, O, K, (int)R, 1, lddy ? lddy : O, K, 1, K, 1, 1, 1, 0, 0, 0, 0, 0, 0, gemm_splits(O, K, R, 1), 1.0f, 2};
         p.asum = G + b_off;
         p.colscale = W + g_off;
         gemm(p);
@@ -456,7 +462,13 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
     // ---- pair transform net, backwards.  dP = gradient wrt the pair representation leaving the current sub-layer.
     auto tri_bwd = [&](const TriOff& t, TriSave& sv, bool outgoing, uint32_t tag) {
         size_t mark = T.off;
-        float* du = T.f(P * cp); float* dgl = T.f(P * cp);
+        // ch == 128: the gradients of the five Linears on LN_in(z) are the column blocks [d ap | d ag | d bp | d bg | d g] of ONE row-major
+        // matrix, so that their input gradients are one GEMM against the five weight matrices stacked (no read-modify-write of dzn)
+        const int ncat5 = 4 * ch + cp;
+        float* du = T.f(P * cp);
+        float* dycat = cmf ? T.f(P * ncat5) : nullptr;
+        float* dgl = cmf ? dycat + 4 * ch : T.f(P * cp);
+        const int ldg = cmf ? ncat5 : cp;
         {
             const float *u = sv.u, *g = sv.g;
             r.ew(P * cp, [=] __device__(long long e) {
@@ -465,7 +477,7 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
                 const float ds_ = r_tri > 0.f ? drop_scale(seed, tag, (uint64_t)((b * N + j) * cp + c), r_tri) : 1.0f;
                 const float dout = dP[e] * ds_;
                 du[e] = dout * g[e];
-                dgl[e] = dout * u[e] * g[e] * (1.0f - g[e]);
+                dgl[row * ldg + c] = dout * u[e] * g[e] * (1.0f - g[e]);
             });
         }
         // linear_z: its weight gradient against xhat_o (gamma as a column scale, beta through the bias gradient)
@@ -495,9 +507,24 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
             r.gemm(ga); r.gemm(gb);
         }
         float *dap, *dag, *dbp, *dbg;
+        float* dzn;
         if (cmf) {              // a = ap m s, so  d ap = da m s  and  d ag = da a (1 - s): the projections themselves are not needed
-            dap = dxn; dag = dxcm; dbp = T.f(P * ch); dbg = T.f(P * ch);
-            if (!dry) { ProfScope ps_(h, st, KC_TR_TRANSPOSE); launch_gate_bwd_from_cm(st, dacm, dbcm, sv.acm, sv.bcm, sv.ag, sv.bg, rm, dap, dag, dbp, dbg, B, N, ch); }
+            dap = dycat; dag = dycat + ch; dbp = dycat + 2 * ch; dbg = dycat + 3 * ch;
+            if (!dry) { ProfScope ps_(h, st, KC_TR_TRANSPOSE); launch_gate_bwd_from_cm(st, dacm, dbcm, sv.acm, sv.bcm, sv.ag, sv.bg, rm, dap, dag, dbp, dbg, B, N, ch, ncat5); }
+            // the five weight matrices stacked [4 ch + cp][cp] (in the blob their biases sit between them)
+            float* wcat = T.f((size_t)ncat5 * cp);
+            if (!dry) {
+                const size_t offs[5] = {t.ap_w, t.ag_w, t.bp_w, t.bg_w, t.g_w};
+                for (int k = 0; k < 5; ++k)
+                    (void)hipMemcpyAsync(wcat + (size_t)k * ch * cp, Wd + offs[k], (size_t)(k < 4 ? ch : cp) * cp * 4, hipMemcpyDeviceToDevice, st);
+            }
+            dzn = T.f(P * cp);
+            r.lin_bwd_w_ln(dap, P, ch, sv.xhat, cp, t.ap_w, t.ap_b, t.lni_g, t.lni_b, ncat5);
+            r.lin_bwd_w_ln(dag, P, ch, sv.xhat, cp, t.ag_w, t.ag_b, t.lni_g, t.lni_b, ncat5);
+            r.lin_bwd_w_ln(dbp, P, ch, sv.xhat, cp, t.bp_w, t.bp_b, t.lni_g, t.lni_b, ncat5);
+            r.lin_bwd_w_ln(dbg, P, ch, sv.xhat, cp, t.bg_w, t.bg_b, t.lni_g, t.lni_b, ncat5);
+            r.lin_bwd_w_ln(dgl, P, cp, sv.xhat, cp, t.g_w, t.g_b, t.lni_g, t.lni_b, ncat5);
+            r.lin_bwd_x_ptr(dycat, P, ncat5, wcat, cp, dzn, cp);
         } else {
             float* darm = dxn; float* dbrm = T.f(P * ch);
             r.transpose(dacm, darm, B, N * N, ch, false); r.transpose(dbcm, dbrm, B, N * N, ch, false);
@@ -511,14 +538,14 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
                 dap[e] = da * sa; dag[e] = da * ap[e] * sa * (1.0f - sa);
                 dbp[e] = db * sb; dbg[e] = db * bp[e] * sb * (1.0f - sb);
             });
+            // the five Linears on LN_in(z): weight gradients against xhat, input gradients summed into dzn
+            dzn = T.f(P * cp);
+            r.lin_bwd_w_ln(dap, P, ch, sv.xhat, cp, t.ap_w, t.ap_b, t.lni_g, t.lni_b); r.lin_bwd_x(dap, P, ch, t.ap_w, cp, dzn, cp, false);
+            r.lin_bwd_w_ln(dag, P, ch, sv.xhat, cp, t.ag_w, t.ag_b, t.lni_g, t.lni_b); r.lin_bwd_x(dag, P, ch, t.ag_w, cp, dzn, cp, true);
+            r.lin_bwd_w_ln(dbp, P, ch, sv.xhat, cp, t.bp_w, t.bp_b, t.lni_g, t.lni_b); r.lin_bwd_x(dbp, P, ch, t.bp_w, cp, dzn, cp, true);
+            r.lin_bwd_w_ln(dbg, P, ch, sv.xhat, cp, t.bg_w, t.bg_b, t.lni_g, t.lni_b); r.lin_bwd_x(dbg, P, ch, t.bg_w, cp, dzn, cp, true);
+            r.lin_bwd_w_ln(dgl, P, cp, sv.xhat, cp, t.g_w, t.g_b, t.lni_g, t.lni_b); r.lin_bwd_x(dgl, P, cp, t.g_w, cp, dzn, cp, true);
         }
-        // the five Linears on LN_in(z): weight gradients against xhat, input gradients summed into dzn
-        float* dzn = T.f(P * cp);
-        r.lin_bwd_w_ln(dap, P, ch, sv.xhat, cp, t.ap_w, t.ap_b, t.lni_g, t.lni_b); r.lin_bwd_x(dap, P, ch, t.ap_w, cp, dzn, cp, false);
-        r.lin_bwd_w_ln(dag, P, ch, sv.xhat, cp, t.ag_w, t.ag_b, t.lni_g, t.lni_b); r.lin_bwd_x(dag, P, ch, t.ag_w, cp, dzn, cp, true);
-        r.lin_bwd_w_ln(dbp, P, ch, sv.xhat, cp, t.bp_w, t.bp_b, t.lni_g, t.lni_b); r.lin_bwd_x(dbp, P, ch, t.bp_w, cp, dzn, cp, true);
-        r.lin_bwd_w_ln(dbg, P, ch, sv.xhat, cp, t.bg_w, t.bg_b, t.lni_g, t.lni_b); r.lin_bwd_x(dbg, P, ch, t.bg_w, cp, dzn, cp, true);
-        r.lin_bwd_w_ln(dgl, P, cp, sv.xhat, cp, t.g_w, t.g_b, t.lni_g, t.lni_b); r.lin_bwd_x(dgl, P, cp, t.g_w, cp, dzn, cp, true);
         r.ln_bwd(dzn, sv.xhat, sv.rstd, t.lni_g, t.lni_b, dP, P, cp, true);
         T.off = mark;
     };

@@ -25,7 +25,7 @@ int gemm_splits(long long M, long long N, long long K, long long batch);
 void launch_ln_fwd(hipStream_t st, const float* x, const float* g, const float* b, float* y, float* xhat, float* rstd, long long R, int C);
 void launch_ln_bwd(hipStream_t st, const float* dy, const float* xhat, const float* rstd, const float* g, float* dx, long long R, int C, int accumulate,
                    float* dgamma, float* dbeta);
-void launch_colsum(hipStream_t st, const float* a, const float* w, long long R, int C, float* out_b, float* out_g);
+void launch_colsum(hipStream_t st, const float* a, const float* w, long long R, int C, float* out_b, float* out_g, long long lda = 0);      // lda: row stride of a (0: C)
 void launch_transpose(hipStream_t st, const float* in, float* out, int B, int R, int C, bool to_cm);
 // Fused layout changes around the triangle multiplication's contraction (row-major [B][N N][C] <-> channel-major [B][C][N N]); C = 128 k:
 //   gate_to_cm:       a = ap m sigmoid(ag), b = bp m sigmoid(bg)  (row-major in) -> acm, bcm (channel-major out)
@@ -39,7 +39,7 @@ void launch_ln_from_cm(hipStream_t st, const float* xcm, const float* g, const f
 void launch_ln_bwd_to_cm(hipStream_t st, const float* dy, const float* xhat, const float* rstd, const float* g, float* dxcm, int B, int R, int C,
                          float* dgamma, float* dbeta);
 void launch_gate_bwd_from_cm(hipStream_t st, const float* dacm, const float* dbcm, const float* acm, const float* bcm, const float* ag, const float* bg,
-                             const float* rmask, float* dap, float* dag, float* dbp, float* dbg, int B, int N, int C);
+                             const float* rmask, float* dap, float* dag, float* dbp, float* dbg, int B, int N, int C, int ldo);     // ldo: row stride of the four results
 // dW[o][c] += beta[c] db[o]   (the beta part of a weight gradient taken against xhat, see GemmP::colscale)
 void launch_rank1_add(hipStream_t st, float* dW, const float* beta, const float* db, int O, int C);
 void launch_pair_features(hipStream_t st, const float* trans, const float* rots, const int8_t* codes, const float* rmask, const uint8_t* fstm,

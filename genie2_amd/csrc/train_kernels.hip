@@ -509,7 +509,7 @@ void launch_gemm(hipStream_t st, const GemmP& p_in, int terms) {
         if (!off && ua && ub && p.M % 64 == 0 && p.N % 64 == 0 && p.K % GM_BK == 0 && ks % GM_BK == 0 && p.am < lim && p.ak < lim && p.bk < lim &&
             p.bn < lim && (long long)p.batch * p.nsplit < 65536 && p.M / 64 < 65536) {
             const bool akc = p.ak == 1, bkc = p.bk == 1;
-            if (p.asum && (akc || p.batch != 1)) { launch_colsum(st, p.A, nullptr, p.K, p.M, p.asum, nullptr); p.asum = nullptr; }
+            if (p.asum && (akc || p.batch != 1)) { launch_colsum(st, p.A, nullptr, p.K, p.M, p.asum, nullptr, p.ak); p.asum = nullptr; }
             static const bool nobig = getenv("GENIE_GEMM_NO_BIG") != nullptr;
             const long long big_tiles = (long long)(p.M / 128) * (p.N / 128) * p.batch * p.nsplit;
             if (!nobig && p.M % 128 == 0 && p.N % 128 == 0 && big_tiles >= 256) {
@@ -526,7 +526,7 @@ void launch_gemm(hipStream_t st, const GemmP& p_in, int terms) {
             return;
         }
     }
-    if (p.asum) { launch_colsum(st, p.A, nullptr, p.K, p.M, p.asum, nullptr); p.asum = nullptr; }      // the generic kernel does not carry the row sums
+    if (p.asum) { launch_colsum(st, p.A, nullptr, p.K, p.M, p.asum, nullptr, p.ak); p.asum = nullptr; }      // the generic kernel does not carry the row sums (A: [K][M], row stride ak)
     const long long tiles = (long long)((p.N + 63) / 64) * ((p.M + 63) / 64) * p.batch * p.nsplit;
     const int total = (int)tiles;
     const int wgs_per_cu = GM_WPS;                      // what __launch_bounds__ and the LDS tiles admit per CU
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, co
 // 256 threads = (256 / C) row groups x C columns (C < 256), or one row group looping over the columns; rows of a block are summed
 // in registers, row groups through LDS, blocks with one atomic per column.
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ a, const float* __restrict__ w, long long R, int C, int rows_per_block,
-                                                float* __restrict__ out_b, float* __restrict__ out_g) {
+                                                float* __restrict__ out_b, float* __restrict__ out_g, long long lda) {
     __shared__ float red[2][256];
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ a, con
         for (int c = tid; c < C; c += 256) {
             float sb = 0.f, sg = 0.f;
             for (long long r = r0; r < r1; ++r) {
-                const float v = a[r * C + c];
+                const float v = a[r * lda + c];
                 sb += v;
                 if (w) sg += v * w[r * C + c];
             }
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ a, con
     float sb = 0.f, sg = 0.f;
     if (rg < nrg)
         for (long long r = r0 + rg; r < r1; r += nrg) {
-            const float v = a[r * C + c];
+            const float v = a[r * lda + c];
             sb += v;
             if (w) sg += v * w[r * C + c];
         }
@@ -692,10 +692,10 @@ void launch_ln_bwd(hipStream_t st, const float* dy, const float* xhat, const flo
     rpb = (rpb + 7) / 8 * 8;
     hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)((R + rpb - 1) / rpb)), dim3(256), 0, st, dy, xhat, rstd, g, dx, R, C, accumulate, rpb, dgamma, dbeta);
 }
-void launch_colsum(hipStream_t st, const float* a, const float* w, long long R, int C, float* out_b, float* out_g) {
+void launch_colsum(hipStream_t st, const float* a, const float* w, long long R, int C, float* out_b, float* out_g, long long lda) {
     int rpb = (int)((R + 1023) / 1024);
     if (rpb < 16) rpb = 16;
-    hipLaunchKernelGGL(k_colsum, dim3((unsigned)((R + rpb - 1) / rpb)), dim3(256), 0, st, a, w, R, C, rpb, out_b, out_g);
+    hipLaunchKernelGGL(k_colsum, dim3((unsigned)((R + rpb - 1) / rpb)), dim3(256), 0, st, a, w, R, C, rpb, out_b, out_g, lda > 0 ? lda : C);
 }
 
 // ------------------------------------------------------------------------------------------------ [B][R][C] <-> [B][C][R]

@@ -145,7 +145,7 @@ void launch_ln_bwd_to_cm(hipStream_t st, const float* dy, const float* xhat, con
 __global__ __launch_bounds__(256) void k_gate_bwd_from_cm(const float* __restrict__ dacm, const float* __restrict__ dbcm, const float* __restrict__ acm,
                                                           const float* __restrict__ bcm, const float* __restrict__ ag, const float* __restrict__ bg,
                                                           const float* __restrict__ rmask, float* __restrict__ dap, float* __restrict__ dag,
-                                                          float* __restrict__ dbp, float* __restrict__ dbg, int N, int C) {
+                                                          float* __restrict__ dbp, float* __restrict__ dbg, int N, int C, int ldo) {
     __shared__ float t[4][32][33];
     const int b = blockIdx.z, R = N * N;
     const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -166,14 +166,15 @@ __global__ __launch_bounds__(256) void k_gate_bwd_from_cm(const float* __restric
         const size_t e = base + (size_t)row * C + c0 + tx;
         const float sa = 1.0f / (1.0f + expf(-ag[e])), sb = 1.0f / (1.0f + expf(-bg[e]));
         const float da = t[0][tx][q], db = t[1][tx][q], a = t[2][tx][q], bb = t[3][tx][q];
-        dap[e] = da * m * sa; dag[e] = da * a * (1.0f - sa);
-        dbp[e] = db * m * sb; dbg[e] = db * bb * (1.0f - sb);
+        const size_t o = ((size_t)b * R + row) * ldo + c0 + tx;       // the results may be column blocks of a wider row-major matrix
+        dap[o] = da * m * sa; dag[o] = da * a * (1.0f - sa);
+        dbp[o] = db * m * sb; dbg[o] = db * bb * (1.0f - sb);
     }
 }
 void launch_gate_bwd_from_cm(hipStream_t st, const float* dacm, const float* dbcm, const float* acm, const float* bcm, const float* ag, const float* bg,
-                             const float* rmask, float* dap, float* dag, float* dbp, float* dbg, int B, int N, int C) {
+                             const float* rmask, float* dap, float* dag, float* dbp, float* dbg, int B, int N, int C, int ldo) {
     hipLaunchKernelGGL(k_gate_bwd_from_cm, dim3((N * N + 31) / 32, C / 32, B), dim3(256), 0, st, dacm, dbcm, acm, bcm, ag, bg, rmask, dap, dag, dbp, dbg,
-                       N, C);
+                       N, C, ldo);
 }
 
 __global__ void k_rank1_add(float* __restrict__ dW, const float* __restrict__ beta, const float* __restrict__ db, int O, int C) {
