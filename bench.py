@@ -43,7 +43,7 @@ from genie2_amd import features as F  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0     # same table, "Peak BF16/FP16 MFMA", dense
 PEAK_HBM_GBS = 8000.0
-PMC_TRAFFIC = [os.path.join(ROOT, 'profiles', n) for n in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json')]   # newest first
+PMC_TRAFFIC = [os.path.join(ROOT, 'profiles', n) for n in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')]   # newest first
 KERNEL_OF_CLASS = {'trimul_proj': 'k_trimul_proj', 'trimul_contract': 'k_trimul_contract', 'trimul_out': 'k_trimul_out',
                    'pair_transition': 'k_pair_transition', 'pair_fused_a': 'k_pair_fused<true, false, true>', 'pair_fused_b': 'k_pair_fused<false, true, true>'}
 
