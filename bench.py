@@ -384,6 +384,17 @@ def main():
             dtf = time.perf_counter() - t0
             out['full_loop'] = {'steps': T, 'seconds': dtf, 'batch_steps_per_s': T / dtf, 'structure_steps_per_s': T * B / dtf,
                                 'finite': bool(torch.isfinite(trf).all().item()), 'math': math}
+        if world == 1 and not args.no_extra_legs:
+            # what dense f16 MFMA work THIS device sustains (the transition stage's instruction stream on every CU for 20 ms): the
+            # roofline above is priced against the datasheet peak; under matrix load the chip holds its power budget, not its clock
+            import ctypes as C
+            tf, pms = C.c_double(0.0), C.c_double(0.0)
+            if eng.lib.genie_probe_mfma(C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), 20.0, C.byref(tf), C.byref(pms)) == 0:
+                out['roofline']['sustained_f16_mfma'] = {
+                    'tflops': tf.value, 'probe_ms': pms.value, 'frac_of_peak': tf.value / PEAK_F16_MFMA_TFLOPS,
+                    'kernel_frac_of_sustained': (roof['achieved'] / tf.value) if roof['bound'] == 'mfma' and math == 'hx' else None,
+                    'what': 'genie_probe_mfma: 48 v_mfma_f32_32x32x16_f16 per wave and stage from LDS fragments + ReLU / split + barrier, '
+                            '512 threads on every CU, random operands, about 20 ms'}
         if world == 1 and not args.no_extra_legs and not args.no_train_leg:
             out['train_step'] = train_step_leg(eng, dims, dev)
         if world == 1 and not args.no_cpu_baseline:

@@ -87,6 +87,7 @@ SYMBOLS = {
     'genie_profile_enable': (C.c_int, [C.c_void_p, C.c_int]),
     'genie_profile_read': (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                                      C.POINTER(C.c_int64), C.c_int]),
+    'genie_probe_mfma': (C.c_int, [C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     'genie_workspace_bytes': (C.c_size_t, [C.c_void_p]),
 }
 

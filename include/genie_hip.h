@@ -268,6 +268,13 @@ int genie_profile_enable(genie_handle_t h, int enable);
 int genie_profile_read(genie_handle_t h, const char** names, double* total_ms,
                        int64_t* launches, int cap);
 
+/* What dense f16 MFMA work the device sustains, measured live (csrc/probe_kernels.hip): the instruction stream of one transition stage
+ * of the fused pair chain on every CU for about ms_target milliseconds (<= 0: 20 ms); synchronises.  The roofline is priced against
+ * the datasheet peak (2.5 PFLOP/s dense f16); under matrix load the chip lowers its clock to its power budget and holds about
+ * 1.3 - 1.7 PFLOP/s -- bench.py prints this number next to the kernels' own matrix rate.  No handle: nothing of the path calls it.
+ * Returns 0 and TFLOP/s in *tflops_out (the launch's milliseconds in *ms_out if not NULL). */
+int genie_probe_mfma(genie_stream_t stream, double ms_target, double* tflops_out, double* ms_out);
+
 /* Workspace bytes currently held (HBM layout report for DESIGN.md). */
 size_t genie_workspace_bytes(genie_handle_t h);
 

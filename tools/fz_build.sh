@@ -7,7 +7,7 @@ TAG=$1; shift
 mkdir -p genie2_amd/lib/abl
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DGENIE_BUILD "$@" -c genie2_amd/csrc/pair_fused_kernels.hip -o genie2_amd/lib/abl/fz_$TAG.o
 OBJS=""
-for f in pair_kernels pair_wl_kernels pair_hx_kernels single_kernels train_kernels train_layout_kernels genie_train genie_api; do OBJS="$OBJS genie2_amd/lib/$f.o"; done
+for f in pair_kernels pair_wl_kernels pair_hx_kernels single_kernels train_kernels train_layout_kernels probe_kernels genie_train genie_api; do OBJS="$OBJS genie2_amd/lib/$f.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o genie2_amd/lib/abl/libgenie_fz_$TAG.so genie2_amd/lib/abl/fz_$TAG.o $OBJS
 rm genie2_amd/lib/abl/fz_$TAG.o
 echo genie2_amd/lib/abl/libgenie_fz_$TAG.so
