@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libgenie_hip.so')
 SOURCES = ['pair_kernels.hip', 'pair_wl_kernels.hip', 'pair_hx_kernels.hip', 'pair_fused_kernels.hip', 'single_kernels.hip', 'train_kernels.hip', 'train_layout_kernels.hip', 'probe_kernels.hip', 'genie_train.hip', 'genie_api.hip']
-HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'hx.h'), os.path.join(CSRC, 'hx_pair.h'), os.path.join(CSRC, 'train.h'), os.path.join(HERE, '..', 'include', 'genie_hip.h')]
+HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'hx.h'), os.path.join(CSRC, 'hx_pair.h'), os.path.join(CSRC, 'hx_fused.h'), os.path.join(CSRC, 'train.h'), os.path.join(HERE, '..', 'include', 'genie_hip.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function', '-Wno-unused-value',
          '-DGENIE_BUILD'] + os.environ.get('GENIE_EXTRA_FLAGS', '').split()
