@@ -549,6 +549,9 @@ __global__ __launch_bounds__(512, 1) void k_trimul_contract_hx_big(const unsigne
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const float v = acc[m][n][r] * cx;
+#if HX_ABL & 512      // developer knock-out (timing only): one store in sixteen
+                            if (r == 0)
+#endif
                             hx_store(rx, v, vst, sbase + ((r & 3) + 8 * (r >> 2)) * NP * 4);
                         }
                     }
