@@ -260,7 +260,6 @@ def main():
     os.dup2(2, 1)
     if dist:
         import torch.distributed as td
-        td.init_process_group('nccl', device_id=dev)
 
     dims = dict(pack.BASE_DIMS)
     B, N, T = args.batch, args.length, dims['n_timestep']
@@ -274,6 +273,13 @@ def main():
     g = torch.Generator().manual_seed(42 + rank)
     P = max(1, args.profile_steps)
     noise = torch.randn(T, B, N, 3, generator=g).to(dev)   # draws of the whole loop: 1 initial + one per step but the last (base.py:227,269)
+
+    if dist:
+        # The process group comes up AFTER the engine (its streams, workspace, the noise): created after RCCL's own streams, the engine's
+        # second stream -- the structure net's two batch halves, DESIGN.md 4.6 -- shares a hardware queue with the first and the step
+        # runs 9 % slower (101.7 vs 110.5 batch-steps/s at one rank, the same kernels; GENIE_NO_STRUCT_SPLIT=1 is immune: 109.3).
+        torch.cuda.synchronize(dev)
+        td.init_process_group('nccl', device_id=dev)
 
     def barrier():
         if dist:
