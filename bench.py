@@ -78,7 +78,7 @@ def kernels_sha():
     h = hashlib.sha256()
     d = os.path.join(ROOT, 'genie2_amd', 'csrc')
     for n in sorted(os.listdir(d)):
-        if n in ('train.h', 'train_kernels.hip', 'genie_train.hip'):
+        if n in ('train.h', 'train_kernels.hip', 'train_layout_kernels.hip', 'genie_train.hip'):
             continue
         h.update(open(os.path.join(d, n), 'rb').read())
     return h.hexdigest()[:16]

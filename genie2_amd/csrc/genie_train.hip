@@ -84,12 +84,13 @@ struct StructSave {
 };
 }  // namespace
 
-struct genie_train_ws { void* kept = nullptr; size_t kept_bytes = 0; void* tmp = nullptr; size_t tmp_bytes = 0; };
+struct genie_train_ws { void* kept = nullptr; size_t kept_bytes = 0; void* tmp = nullptr; size_t tmp_bytes = 0; FoldEntry* fold_tab = nullptr; int fold_n = 0; };
 
 void train_ws_free(genie_ctx* h) {
     if (!h->train) return;
     if (h->train->kept) (void)hipFree(h->train->kept);
     if (h->train->tmp) (void)hipFree(h->train->tmp);
+    if (h->train->fold_tab) (void)hipFree(h->train->fold_tab);
     delete h->train;
     h->train = nullptr;
 }
@@ -149,6 +150,13 @@ struct Run {
         if (!G) return;                     // input-gradient only (genie_denoise_vjp)
         GemmP p{dY, X, G + w, nullptr, O, K, (int)R, 1, O, ldx, 1, K, 1, 1, 1, 0, 0, 0, 0, 0, 0, gemm_splits(O, K, R, 1), 1.0f, 2};
         p.asum = b_off >= 0 ? G + b_off : nullptr;      // db: the column sums of dY, taken while the GEMM streams it
+        gemm(p);
+    }
+    // Y[R][O] = (xhat gamma + beta) W^T + b without forming xhat gamma + beta: the Linear's weights folded with the LayerNorm's affine
+    // (`fold`: O K + O floats written by launch_fold_ln_table at the start of the pass) applied to xhat
+    void lin_fwd_ln(const float* Xhat, long long R, int K, int O, float* Y, const float* fold, bool relu = false) {
+        GemmP p{Xhat, fold, Y, fold ? fold + (size_t)O * K : nullptr, (int)R, O, K, K, 1, 1, K, O, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0f, 0};
+        p.relu = relu ? 1 : 0;
         gemm(p);
     }
     // dW[O][K] += dY^T (xhat gamma + beta) without forming xhat gamma + beta:  gamma[k] (dY^T xhat)[o][k]  +  beta[k] db[o]
@@ -237,19 +245,57 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         T.off = mark;
     }
     std::vector<PairSave> ps(L);
+    // Every Linear of the pair stack that follows a LayerNorm runs on xhat with the LayerNorm's affine folded into its weights; all
+    // 6 L x 2 + L folds in ONE launch here (the table of blob offsets depends on the dims only and is uploaded once per handle)
+    std::vector<FoldEntry> fold_plan;
+    std::vector<size_t> fold_tri((size_t)L * 2 * 6), fold_tr(L);
+    size_t fold_floats = 0;
+    {
+        auto plan = [&](size_t w, size_t b, size_t g, size_t be, int Oo, int Kk) {
+            fold_plan.push_back(FoldEntry{(long long)w, (long long)b, (long long)g, (long long)be, (long long)fold_floats, Oo, Kk});
+            const size_t at = fold_floats;
+            fold_floats += ((size_t)Oo * Kk + Oo + 63) / 64 * 64;
+            return at;
+        };
+        for (int l = 0; l < L; ++l) {
+            for (int dir = 0; dir < 2; ++dir) {
+                const TriOff& t = dir == 0 ? O.pair[l].out : O.pair[l].in;
+                size_t* f = &fold_tri[((size_t)l * 2 + dir) * 6];
+                f[0] = plan(t.ap_w, t.ap_b, t.lni_g, t.lni_b, ch, cp); f[1] = plan(t.ag_w, t.ag_b, t.lni_g, t.lni_b, ch, cp);
+                f[2] = plan(t.bp_w, t.bp_b, t.lni_g, t.lni_b, ch, cp); f[3] = plan(t.bg_w, t.bg_b, t.lni_g, t.lni_b, ch, cp);
+                f[4] = plan(t.g_w, t.g_b, t.lni_g, t.lni_b, cp, cp); f[5] = plan(t.z_w, t.z_b, t.lno_g, t.lno_b, cp, ch);
+            }
+            fold_tr[l] = plan(O.pair[l].w1, O.pair[l].b1, O.pair[l].ln_g, O.pair[l].ln_b, nh, cp);
+        }
+    }
+    float* foldbuf = K.f(fold_floats);
+    if (!dry && !fold_plan.empty()) {
+        genie_train_ws* tw = h->train;
+        if (tw->fold_n != (int)fold_plan.size()) {
+            if (tw->fold_tab) (void)hipFree(tw->fold_tab);
+            (void)hipMalloc((void**)&tw->fold_tab, fold_plan.size() * sizeof(FoldEntry));
+            (void)hipMemcpyAsync(tw->fold_tab, fold_plan.data(), fold_plan.size() * sizeof(FoldEntry), hipMemcpyHostToDevice, st);
+            (void)hipStreamSynchronize(st);          // (once per handle: the host vector goes out of scope)
+            tw->fold_n = (int)fold_plan.size();
+        }
+        ProfScope ps_(h, st, KC_TR_EW);
+        launch_fold_ln_table(st, Wd, foldbuf, tw->fold_tab, tw->fold_n, nh > ch ? (nh > cp ? nh : cp) : (ch > cp ? ch : cp));
+    }
     // ch == 128: the gate / LayerNorm passes next to the contraction are fused with its layout changes (train_layout_kernels.hip) and the
     // projections ap, bp are temporaries (the backward pass works from a, b themselves)
     const bool cmf = train_cm_fusable(ch);
-    auto tri_fwd = [&](const TriOff& t, TriSave& s, bool outgoing, uint32_t tag) {
+    auto tri_fwd = [&](const TriOff& t, TriSave& s, bool outgoing, uint32_t tag, const size_t* fo) {
         s.xhat = K.f(P * cp); s.rstd = K.f(P); s.ag = K.f(P * ch); s.bg = K.f(P * ch);
         if (!cmf) { s.ap = K.f(P * ch); s.bp = K.f(P * ch); }
         s.acm = K.f(P * ch); s.bcm = K.f(P * ch); s.xhat_o = K.f(P * ch); s.rstd_o = K.f(P); s.u = K.f(P * cp); s.g = K.f(P * cp);
         size_t mark = T.off;
-        float* zn = T.f(P * cp);
         if (cmf) { s.ap = T.f(P * ch); s.bp = T.f(P * ch); }
-        r.ln_fwd(z, t.lni_g, t.lni_b, zn, s.xhat, s.rstd, P, cp);
-        r.lin_fwd(zn, cp, P, cp, t.ap_w, t.ap_b, ch, s.ap); r.lin_fwd(zn, cp, P, cp, t.ag_w, t.ag_b, ch, s.ag);
-        r.lin_fwd(zn, cp, P, cp, t.bp_w, t.bp_b, ch, s.bp); r.lin_fwd(zn, cp, P, cp, t.bg_w, t.bg_b, ch, s.bg);
+        r.ln_fwd(z, t.lni_g, t.lni_b, nullptr, s.xhat, s.rstd, P, cp);                                  // (xhat only: the Linears below run on folded weights)
+        auto fw = [&](int k) -> const float* { return dry ? nullptr : foldbuf + fo[k]; };
+        r.lin_fwd_ln(s.xhat, P, cp, ch, s.ap, fw(0));
+        r.lin_fwd_ln(s.xhat, P, cp, ch, s.ag, fw(1));
+        r.lin_fwd_ln(s.xhat, P, cp, ch, s.bp, fw(2));
+        r.lin_fwd_ln(s.xhat, P, cp, ch, s.bg, fw(3));
         float *xcm, *xn;
         if (cmf) {
             if (!dry) { ProfScope ps_(h, st, KC_TR_TRANSPOSE); launch_gate_to_cm(st, s.ap, s.ag, s.bp, s.bg, rm, s.acm, s.bcm, B, N, ch); }
@@ -274,15 +320,16 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
             else { g.am = 1; g.ak = N; g.bk = N; g.bn = 1; }               // x[i][j] = sum_k a[k][i] b[k][j]
             r.gemm(g);
         }
+        (void)xn;
         if (cmf) {
-            if (!dry) { ProfScope ps_(h, st, KC_TR_LN); launch_ln_from_cm(st, xcm, Wd + t.lno_g, Wd + t.lno_b, xn, s.xhat_o, s.rstd_o, B, N * N, ch); }
+            if (!dry) { ProfScope ps_(h, st, KC_TR_LN); launch_ln_from_cm(st, xcm, Wd + t.lno_g, Wd + t.lno_b, nullptr, s.xhat_o, s.rstd_o, B, N * N, ch); }
         } else {
             float* xrm = T.f(P * ch);
             r.transpose(xcm, xrm, B, N * N, ch, false);
-            r.ln_fwd(xrm, t.lno_g, t.lno_b, xn, s.xhat_o, s.rstd_o, P, ch);
+            r.ln_fwd(xrm, t.lno_g, t.lno_b, nullptr, s.xhat_o, s.rstd_o, P, ch);
         }
-        r.lin_fwd(xn, ch, P, ch, t.z_w, t.z_b, cp, s.u);
-        r.lin_fwd(zn, cp, P, cp, t.g_w, t.g_b, cp, s.g);
+        r.lin_fwd_ln(s.xhat_o, P, ch, cp, s.u, fw(5));
+        r.lin_fwd_ln(s.xhat, P, cp, cp, s.g, fw(4));
         {
             float *u = s.u, *g = s.g;
             r.ew(P * cp, [=] __device__(long long e) {
@@ -297,15 +344,15 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         T.off = mark;
     };
     for (int l = 0; l < L; ++l) {
-        tri_fwd(O.pair[l].out, ps[l].out, true, (uint32_t)(4 * l));
-        tri_fwd(O.pair[l].in, ps[l].in, false, (uint32_t)(4 * l + 1));
+        tri_fwd(O.pair[l].out, ps[l].out, true, (uint32_t)(4 * l), &fold_tri[((size_t)l * 2) * 6]);
+        tri_fwd(O.pair[l].in, ps[l].in, false, (uint32_t)(4 * l + 1), &fold_tri[((size_t)l * 2 + 1) * 6]);
         TransSave& s = ps[l].tr;
         const PairOff& o = O.pair[l];
         s.xhat = K.f(P * cp); s.rstd = K.f(P); s.h = K.f(P * nh);
         size_t mark = T.off;
-        float* zn = T.f(P * cp); float* ot = T.f(P * cp);
-        r.ln_fwd(z, o.ln_g, o.ln_b, zn, s.xhat, s.rstd, P, cp);
-        r.lin_fwd(zn, cp, P, cp, o.w1, o.b1, nh, s.h, 0, true);          // Linear + ReLU
+        float* ot = T.f(P * cp);
+        r.ln_fwd(z, o.ln_g, o.ln_b, nullptr, s.xhat, s.rstd, P, cp);
+        r.lin_fwd_ln(s.xhat, P, cp, nh, s.h, dry ? nullptr : foldbuf + fold_tr[l], true);          // LayerNorm's affine folded into Linear + ReLU
         r.lin_fwd(s.h, nh, P, nh, o.w2, o.b2, cp, ot);
         r.ew(P * cp, [=] __device__(long long e) {
             const long long row = e / cp; const int j = (int)(row % N); const long long bi = row / N; const long long b = bi / N;

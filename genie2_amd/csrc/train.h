@@ -40,6 +40,12 @@ void launch_ln_bwd_to_cm(hipStream_t st, const float* dy, const float* xhat, con
                          float* dgamma, float* dbeta);
 void launch_gate_bwd_from_cm(hipStream_t st, const float* dacm, const float* dbcm, const float* acm, const float* bcm, const float* ag, const float* bg,
                              const float* rmask, float* dap, float* dag, float* dbp, float* dbg, int B, int N, int C, int ldo);     // ldo: row stride of the four results
+// A Linear applied to LayerNorm's output without materialising it:  (xhat gamma + beta) W^T + b  =  xhat (W gamma)^T + (W beta + b):
+//   Wf[o][k] = W[o][k] gamma[k],   bf[o] = b[o] + sum_k W[o][k] beta[k]          (b may be NULL)
+void launch_fold_ln(hipStream_t st, const float* W, const float* b, const float* gamma, const float* beta, float* Wf, float* bf, int O, int K);
+// ... for a table of Linears in one launch (all offsets into the weight blob `wts` / the scratch `dst`; b < 0: no bias)
+struct FoldEntry { long long w, b, g, beta, dst; int O, K; };
+void launch_fold_ln_table(hipStream_t st, const float* wts, float* dst, const FoldEntry* table_dev, int n_entries, int max_O);
 // dW[o][c] += beta[c] db[o]   (the beta part of a weight gradient taken against xhat, see GemmP::colscale)
 void launch_rank1_add(hipStream_t st, float* dW, const float* beta, const float* db, int O, int C);
 void launch_pair_features(hipStream_t st, const float* trans, const float* rots, const int8_t* codes, const float* rmask, const uint8_t* fstm,

@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, con
         if (c < C) {
             const float xh = (v[q] - mean) * rs;
             if (xhat) xhat[row * C + c] = xh;
-            y[row * C + c] = xh * g[c] + b[c];
+            if (y) y[row * C + c] = xh * g[c] + b[c];
         }
     }
 }

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_ln_from_cm(const float* __restrict__ xc
         xh.x = (t[4 * tx][q] - mean) * rs; xh.y = (t[4 * tx + 1][q] - mean) * rs; xh.z = (t[4 * tx + 2][q] - mean) * rs; xh.w = (t[4 * tx + 3][q] - mean) * rs;
         const size_t e = ((size_t)b * R + row) * C + 4 * tx;
         *reinterpret_cast<float4*>(xhat + e) = xh;
-        *reinterpret_cast<float4*>(y + e) = make_float4(xh.x * gv.x + bv.x, xh.y * gv.y + bv.y, xh.z * gv.z + bv.z, xh.w * gv.w + bv.w);
+        if (y) *reinterpret_cast<float4*>(y + e) = make_float4(xh.x * gv.x + bv.x, xh.y * gv.y + bv.y, xh.z * gv.z + bv.z, xh.w * gv.w + bv.w);
         if (tx == 0) rstd[(size_t)b * R + row] = rs;
     }
 }
@@ -183,4 +183,43 @@ __global__ void k_rank1_add(float* __restrict__ dW, const float* __restrict__ be
 }
 void launch_rank1_add(hipStream_t st, float* dW, const float* beta, const float* db, int O, int C) {
     hipLaunchKernelGGL(k_rank1_add, dim3((O * C + 255) / 256), dim3(256), 0, st, dW, beta, db, O, C);
+}
+
+// one wave per output row o: Wf[o][:] = W[o][:] * gamma, bf[o] = b[o] + <W[o][:], beta>
+__global__ __launch_bounds__(256) void k_fold_ln(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, float* __restrict__ Wf, float* __restrict__ bf, int O, int K) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (o >= O) return;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = W[(size_t)o * K + k];
+        Wf[(size_t)o * K + k] = w * gamma[k];
+        s += w * beta[k];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) bf[o] = (b ? b[o] : 0.f) + s;
+}
+void launch_fold_ln(hipStream_t st, const float* W, const float* b, const float* gamma, const float* beta, float* Wf, float* bf, int O, int K) {
+    hipLaunchKernelGGL(k_fold_ln, dim3((O + 3) / 4), dim3(256), 0, st, W, b, gamma, beta, Wf, bf, O, K);
+}
+
+__global__ __launch_bounds__(256) void k_fold_ln_table(const float* __restrict__ wts, float* __restrict__ dst, const FoldEntry* __restrict__ tab) {
+    const FoldEntry e = tab[blockIdx.y];
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (o >= e.O) return;
+    const float* W = wts + e.w + (size_t)o * e.K;
+    float* Wf = dst + e.dst + (size_t)o * e.K;
+    float s = 0.f;
+    for (int k = lane; k < e.K; k += 64) {
+        const float w = W[k];
+        Wf[k] = w * wts[e.g + k];
+        s += w * wts[e.beta + k];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) dst[e.dst + (size_t)e.O * e.K + o] = (e.b >= 0 ? wts[e.b + o] : 0.f) + s;
+}
+void launch_fold_ln_table(hipStream_t st, const float* wts, float* dst, const FoldEntry* table_dev, int n_entries, int max_O) {
+    if (n_entries > 0) hipLaunchKernelGGL(k_fold_ln_table, dim3((max_O + 3) / 4, n_entries), dim3(256), 0, st, wts, dst, table_dev);
 }
