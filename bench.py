@@ -275,9 +275,10 @@ def main():
     noise = torch.randn(T, B, N, 3, generator=g).to(dev)   # draws of the whole loop: 1 initial + one per step but the last (base.py:227,269)
 
     if dist:
-        # The process group comes up AFTER the engine (its streams, workspace, the noise): created after RCCL's own streams, the engine's
-        # second stream -- the structure net's two batch halves, DESIGN.md 4.6 -- shares a hardware queue with the first and the step
-        # runs 9 % slower (101.7 vs 110.5 batch-steps/s at one rank, the same kernels; GENIE_NO_STRUCT_SPLIT=1 is immune: 109.3).
+        # The process group comes up AFTER the engine (its streams, workspace, the noise): created after RCCL's own streams, a
+        # default-priority second stream of the engine -- the structure net's two batch halves, DESIGN.md 4.6 -- shared a hardware
+        # queue with the first and the step ran 9 % slower (101.7 vs 110.5 batch-steps/s at one rank).  The library now creates that
+        # stream with a non-default priority, which cures it; the order here is kept as the belt to those braces.
         torch.cuda.synchronize(dev)
         td.init_process_group('nccl', device_id=dev)
 
