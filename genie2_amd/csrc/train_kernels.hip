@@ -1075,19 +1075,52 @@ __global__ __launch_bounds__(IPA_NT) void k_ipa_bwd_q(IpaDims d, const float* __
         }
     }
     __syncthreads();
-    for (int u = tid; u < ((d.skip & 4) ? 0 : H * C); u += IPA_NT) {          // dq
-        const int h = u / C, c = u % C;
-        float s = 0.f;
+    {   // dq and dq_pts (global): sums over the N keys of d logit x (k_j | q_pt - k_pt_j).  One thread per (output, third of the key
+        // range) -- every output alone on a thread walked all N keys as a chain of L2 round trips with 336 of the 1024 threads busy --
+        // partial sums meet in LDS (the pair-row tile of the first phase is free by now)
+        const int nq = H * C, np = H * Pq * 3, nout = nq + np;
+        const int G = IPA_NT / nout;                                   // key-range groups (3 for the released models)
+        float* part = red + 16;                                        // [G][nout]
+        const int o = tid % nout, g = tid / nout;
+        if (G == 0) {           // more outputs than threads (not a released shape): every output walks all keys
+            for (int u = tid; u < ((d.skip & 4) ? 0 : nq); u += IPA_NT) {
+                const int h = u / C, c = u % C;
+                float sacc = 0.f;
+                for (int j = 0; j < N; ++j) sacc += dat[h * N + j] * kv[(((size_t)b * N + j) * H + h) * 2 * C + c];
+                dq[(size_t)bi * nq + u] = sacc * d.c_qk;
+            }
+            for (int u = tid; u < ((d.skip & 8) ? 0 : np); u += IPA_NT) {
+                const int h = u / (Pq * 3), t = u % (Pq * 3);
+                float sacc = 0.f;
+                for (int j = 0; j < N; ++j) sacc += dat[h * N + j] * (sqp[u] - kp[(((size_t)b * N + j) * H + h) * Pq * 3 + t]);
+                dqp[(size_t)bi * np + u] = -softplus_dev(head_w[h]) * cpt * sacc;
+            }
+        } else if (g < G && !(o < nq ? (d.skip & 4) : (d.skip & 8))) {
+            const int jb = (int)((long long)N * g / G), je = (int)((long long)N * (g + 1) / G);
+            float sacc = 0.f;
+            if (o < nq) {
+                const int h = o / C, c = o % C;
 #pragma unroll 8
-        for (int j = 0; j < N; ++j) s += dat[h * N + j] * kv[(((size_t)b * N + j) * H + h) * 2 * C + c];
-        dq[(size_t)bi * H * C + u] = s * d.c_qk;
-    }
-    for (int u = tid; u < ((d.skip & 8) ? 0 : H * Pq * 3); u += IPA_NT) {     // dq_pts (global): -hw sum_j dlogit (qp - kp_j)
-        const int h = u / (Pq * 3), t = u % (Pq * 3);
-        float s = 0.f;
+                for (int j = jb; j < je; ++j) sacc += dat[h * N + j] * kv[(((size_t)b * N + j) * H + h) * 2 * C + c];
+            } else {
+                const int u = o - nq, h = u / (Pq * 3), t = u % (Pq * 3);
+                const float qv = sqp[u];
 #pragma unroll 8
-        for (int j = 0; j < N; ++j) s += dat[h * N + j] * (sqp[u] - kp[(((size_t)b * N + j) * H + h) * Pq * 3 + t]);
-        dqp[(size_t)bi * H * Pq * 3 + u] = -softplus_dev(head_w[h]) * cpt * s;
+                for (int j = jb; j < je; ++j) sacc += dat[h * N + j] * (qv - kp[(((size_t)b * N + j) * H + h) * Pq * 3 + t]);
+            }
+            part[g * nout + o] = sacc;
+        }
+        __syncthreads();
+        if (G > 0 && tid < nout && !(tid < nq ? (d.skip & 4) : (d.skip & 8))) {
+            float sacc = 0.f;
+            for (int gg = 0; gg < G; ++gg) sacc += part[gg * nout + tid];
+            if (tid < nq) dq[(size_t)bi * nq + tid] = sacc * d.c_qk;
+            else {
+                const int u = tid - nq, h = u / (Pq * 3);
+                dqp[(size_t)bi * np + u] = -softplus_dev(head_w[h]) * cpt * sacc;
+            }
+        }
+        __syncthreads();
     }
     // pair gradient rows (b, i, j, :) += sum_h att do_pair + c_b dlogit W_b
     if (d.skip & 16) return;
