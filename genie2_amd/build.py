@@ -46,7 +46,8 @@ def build(force=False):
     os.makedirs(LIBDIR, exist_ok=True)
     if force:
         for f in os.listdir(LIBDIR):
-            os.remove(os.path.join(LIBDIR, f))
+            if os.path.isfile(os.path.join(LIBDIR, f)):      # (lib/abl/ holds developer variant builds)
+                os.remove(os.path.join(LIBDIR, f))
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(_compile, SOURCES))
     if not _newer(LIB, objs):
