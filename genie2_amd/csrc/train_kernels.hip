@@ -1036,11 +1036,24 @@ __global__ __launch_bounds__(IPA_NT) void k_ipa_bwd_q(IpaDims d, const float* __
                     if (h >= H) continue;
                     float sacc = acc[t];
                     const float* vr = kv + (mj * H + h) * 2 * C + C;
-#pragma unroll 8
-                    for (int c = 0; c < C; ++c) sacc += sdo[h * C + c] * vr[c];
                     const float* vpr = vp + (mj * H + h) * Pv * 3;
+                    if (C % 4 == 0 && (Pv * 3) % 4 == 0) {      // a lane owns these rows: 16-byte loads instead of one round trip per float
 #pragma unroll 4
-                    for (int q3 = 0; q3 < Pv * 3; ++q3) sacc += sdg[h * Pv * 3 + q3] * vpr[q3];
+                        for (int c = 0; c < C; c += 4) {
+                            const float4 x = *reinterpret_cast<const float4*>(vr + c);
+                            sacc += (sdo[h * C + c] * x.x + sdo[h * C + c + 1] * x.y) + (sdo[h * C + c + 2] * x.z + sdo[h * C + c + 3] * x.w);
+                        }
+#pragma unroll 6
+                        for (int q3 = 0; q3 < Pv * 3; q3 += 4) {
+                            const float4 x = *reinterpret_cast<const float4*>(vpr + q3);
+                            sacc += (sdg[h * Pv * 3 + q3] * x.x + sdg[h * Pv * 3 + q3 + 1] * x.y) + (sdg[h * Pv * 3 + q3 + 2] * x.z + sdg[h * Pv * 3 + q3 + 3] * x.w);
+                        }
+                    } else {
+#pragma unroll 8
+                        for (int c = 0; c < C; ++c) sacc += sdo[h * C + c] * vr[c];
+#pragma unroll 4
+                        for (int q3 = 0; q3 < Pv * 3; ++q3) sacc += sdg[h * Pv * 3 + q3] * vpr[q3];
+                    }
                     dat[h * N + j] = sacc;
                 }
             }
@@ -1062,8 +1075,17 @@ __global__ __launch_bounds__(IPA_NT) void k_ipa_bwd_q(IpaDims d, const float* __
                 sb += g;
                 float ds = 0.f;
                 const float* kpr = kp + (((size_t)b * N + j) * H + h) * Pq * 3;
+                if ((Pq * 3) % 4 == 0) {
+#pragma unroll 3
+                    for (int t = 0; t < Pq * 3; t += 4) {
+                        const float4 x = *reinterpret_cast<const float4*>(kpr + t);
+                        const float d0 = sqp[h * Pq * 3 + t] - x.x, d1 = sqp[h * Pq * 3 + t + 1] - x.y, d2 = sqp[h * Pq * 3 + t + 2] - x.z, d3 = sqp[h * Pq * 3 + t + 3] - x.w;
+                        ds += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                    }
+                } else {
 #pragma unroll 4
-                for (int t = 0; t < Pq * 3; ++t) { const float df = sqp[h * Pq * 3 + t] - kpr[t]; ds += df * df; }
+                    for (int t = 0; t < Pq * 3; ++t) { const float df = sqp[h * Pq * 3 + t] - kpr[t]; ds += df * df; }
+                }
                 sh += g * ds;
             }
             for (int o = 32; o > 0; o >>= 1) { sb += __shfl_xor(sb, o); sh += __shfl_xor(sh, o); }
