@@ -46,7 +46,11 @@ __global__ __launch_bounds__(T, 1) void probe(float* out, int iters, long long* 
             for (int kc = 0; kc < 8; ++kc) {
                 const h8 nh = LDSR ? frag(stage, kc < 7 ? kc + 1 : 7, 0, lane) : wh, nl = LDSR ? frag(stage, kc < 7 ? kc + 1 : 7, 1, lane) : wl;
                 FENCE();
+#ifdef ORDER2      /* (lo,hi) (hi,hi) (hi,lo): each operand changes once per triple */
+                if (DEP) { MFH(wl, zh[kc], d); MFH(wh, zh[kc], d); MFH(wh, zl[kc], d); }
+#else
                 if (DEP) { MFH(wl, zh[kc], d); MFH(wh, zl[kc], d); MFH(wh, zh[kc], d); }
+#endif
                 else { MFH(wl, zh[kc], d); MFH(wh, zl[kc], x1); MFH(wh, zh[kc], x2); }
                 FENCE();
                 wh = nh; wl = nl;
@@ -70,7 +74,11 @@ __global__ __launch_bounds__(T, 1) void probe(float* out, int iters, long long* 
             for (int u = 0; u < 8; ++u) {
                 const h8 nh = LDSR ? frag(stage, 8 + (u < 7 ? u + 1 : 7), 0, lane) : bh, nl = LDSR ? frag(stage, 8 + (u < 7 ? u + 1 : 7), 1, lane) : bl;
                 FENCE();
+#ifdef ORDER2
+                if (DEP) { MFH(bl, ah[u >> 2], v[u & 3]); MFH(bh, ah[u >> 2], v[u & 3]); MFH(bh, al[u >> 2], v[u & 3]); }
+#else
                 if (DEP) { MFH(bl, ah[u >> 2], v[u & 3]); MFH(bh, al[u >> 2], v[u & 3]); MFH(bh, ah[u >> 2], v[u & 3]); }
+#endif
                 else { MFH(bl, ah[u >> 2], v[u & 3]); MFH(bh, al[u >> 2], v[(u + 1) & 3]); MFH(bh, ah[u >> 2], v[(u + 2) & 3]); }
                 FENCE();
                 bh = nh; bl = nl;
