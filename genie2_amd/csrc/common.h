@@ -258,6 +258,7 @@ struct genie_ctx {
     unsigned *pmax;               // bits of max |p| over the pair tensor the IPA layers read (k_ipa_bias -> k_ipa_attn_q)
     float *xsingle, *s0, *s, *s1, *s2, *h1, *h2, *pij, *proj, *cat;
     float *kT, *v, *qp, *kpT, *vp;
+    float *vf, *vmax;      // hx attention: V / v_pts rows as f32 MFMA B fragments, and each row's largest |v|, |v_pt| (single_kernels.hip k_ipa_prep)
     float *rots_w, *trans_w;      // working frames
     int32_t* tsteps;              // [B] uniform timestep buffer for the loop
     float *loop_z;                // [B,N,3]
@@ -289,6 +290,7 @@ bool launch_pair_stack_fused(genie_ctx* h, hipStream_t st, float* tap_trimul_out
 void launch_ipa_bias(genie_ctx* h, hipStream_t st);
 void launch_ipa_prep(genie_ctx* h, hipStream_t st, int b0 = 0, int nb = -1);       // batch entries b0 .. b0 + nb - 1 (nb < 0: all)
 void launch_ipa_attn(genie_ctx* h, hipStream_t st, int layer, const float* head_w, int b0 = 0, int nb = -1);
+size_t ipa_vf_floats(const genie_dims_t& d, int B, int N);      // size of genie_ctx::vf
 bool ipa_attn_splits(const genie_ctx* h);         // the attention kernel in use takes a batch range
 void launch_q_sample(genie_ctx* h, hipStream_t st, const float* x0, const float* z, const float* c0, const float* c1, float* trans_out);
 void launch_training_loss(genie_ctx* h, hipStream_t st, const float* zp, const float* z, float w, float* losses, float* grad);

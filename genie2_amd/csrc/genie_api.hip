@@ -571,6 +571,7 @@ int genie_prepare_features(genie_handle_t h, genie_stream_t stream, int B, int N
     want(&h->pij, M * 2 * cp * 4); want(&h->proj, M * ipa_proj_n(d) * 4); want(&h->cat, M * ipa_cat_n(d) * 4);
     want(&h->kT, M * H * C * 4); want(&h->v, M * H * C * 4); want(&h->qp, M * H * Pq * 3 * 4);
     want(&h->kpT, M * H * Pq * 3 * 4); want(&h->vp, M * H * Pv * 3 * 4);
+    want(&h->vf, ipa_vf_floats(d, B, N) * 4); want(&h->vmax, M * 2 * 4);
     want(&h->rots_w, M * 9 * 4); want(&h->trans_w, M * 3 * 4); want(&h->loop_z, M * 3 * 4);
     want(&h->tsteps, (size_t)B * 4); want(&h->rmaskf, M * 4); want(&h->pmax, 4); want(&h->spart, 3 * M * cs * 4);      // SR_KSPLIT slices
     want(&h->f_aatype, M * 20 * 4); want(&h->f_rmask, M * 4); want(&h->f_ridx, M * 4); want(&h->f_cidx, M * 4);
@@ -598,6 +599,7 @@ int genie_prepare_features(genie_handle_t h, genie_stream_t stream, int B, int N
     hipLaunchKernelGGL(k_mask_to_float, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, h->f_rmask, h->rmaskf, (int)M);
     // channel-major TriMul operands rely on zero padding beyond N
     HIP_TRY(h, hipMemsetAsync(h->acm, 0, (size_t)B * cp * NP * NP * 4, st));
+    HIP_TRY(h, hipMemsetAsync(h->vf, 0, ipa_vf_floats(d, B, N) * 4, st));          // fragment rows beyond N and the padding columns stay zero
     HIP_TRY(h, hipMemsetAsync(h->bcm, 0, (size_t)B * cp * NP * NP * 4, st));
     single_kernels_init(d, N);
     {   // does this batch condition on structure (any fixed_structure_mask entry set)?  If not, the motif term is identically

@@ -352,6 +352,105 @@ __global__ void k_ipa_prep(const float* __restrict__ proj, int ldp, const float*
     }
 }
 
+// The same for the hx attention kernel (k_ipa_attn_q<.., MF = 1>, C = 16), which takes a v and a v_pts on the matrix pipe: a work-group
+// owns EIGHT consecutive residues of one structure, so that everything that goes out key-contiguous leaves as 32-byte runs (kT, kpT --
+// 4-byte stores N apart in the one-row form), and V and v_pts go out as the B fragments of v_mfma_f32_16x16x32_f16 instead of row-major:
+//   vf[b][h][block][j / 32][lane = 16 ((j & 31) >> 3) + column][j & 7],   block 0 = the head's 16 channels of v, blocks 1.. = its 3 Pv
+// point coordinates in steps of 16 (padding columns and rows beyond N stay zero) -- still f32: the f16 split needs ONE scale per
+// structure, known only when every row is through; each work-group leaves its largest |v| and |v_pt| in vmax[b][group][2] for that.
+__global__ __launch_bounds__(256) void k_ipa_prep_frag(const float* __restrict__ proj, int ldp, const float* __restrict__ rots,
+                                                       const float* __restrict__ trans, float* __restrict__ kT, float* __restrict__ qp,
+                                                       float* __restrict__ kpT, float* __restrict__ vf, float* __restrict__ vmax,
+                                                       int N, int H, int C, int Pq, int Pv, int b0) {
+    const int G = (N + 7) >> 3, b = b0 + blockIdx.x / G, grp = blockIdx.x % G, j0 = grp * 8;
+    const int KS = (N + 31) >> 5, NBK = 1 + (3 * Pv + 15) / 16;
+    const int HC = H * C, okv = HC, oqp = 3 * HC, okp = 3 * HC + 3 * H * Pq;
+    __shared__ float sR[8][12];
+    __shared__ unsigned smax[2];
+    if (threadIdx.x < 96) {
+        const int e = threadIdx.x / 12, k = threadIdx.x % 12, row = b * N + min(j0 + e, N - 1);
+        sR[e][k] = k < 9 ? rots[(size_t)row * 9 + k] : trans[(size_t)row * 3 + (k - 9)];
+    }
+    if (threadIdx.x < 2) smax[threadIdx.x] = 0u;
+    __syncthreads();
+    const float* pr = proj + (size_t)(b * N + j0) * ldp;
+    const bool vec = (N & 3) == 0;                          // then a run of 8 keys is 16-byte aligned and inside the row
+    auto put8 = [&](float* dst, const float (&x)[8]) {      // keys j0 .. j0 + 7 of a key-contiguous row
+        if (vec && j0 + 8 <= N) {
+            *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[1], x[2], x[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(x[4], x[5], x[6], x[7]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (j0 + e < N) dst[e] = x[e];
+        }
+    };
+    auto put_frag = [&](int hh, int cb, int c, const float (&x)[8]) {        // rows beyond N as zeros
+        float* dst = vf + (((((size_t)b * H + hh) * NBK + cb) * KS + (j0 >> 5)) * 64 + ((j0 & 31) >> 3) * 16 + c) * 8;
+        *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[1], x[2], x[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(x[4], x[5], x[6], x[7]);
+    };
+    float mv = 0.f, mp = 0.f;
+    for (int u = threadIdx.x; u < HC; u += 256) {
+        const int hh = u / C, c = u % C;
+        float k8[8], v8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool ok = j0 + e < N;
+            k8[e] = ok ? pr[(size_t)e * ldp + okv + hh * 2 * C + c] : 0.f;
+            v8[e] = ok ? pr[(size_t)e * ldp + okv + hh * 2 * C + C + c] : 0.f;
+            mv = fmaxf(mv, fabsf(v8[e]));
+        }
+        put8(kT + (((size_t)b * H + hh) * C + c) * N + j0, k8);
+        put_frag(hh, 0, c, v8);
+    }
+    const int nq = H * Pq, nkv = H * (Pq + Pv);
+    for (int u = threadIdx.x; u < nq + nkv; u += 256) {
+        const bool isq = u < nq;
+        const int idx = isq ? u : u - nq;
+        const int blk = isq ? nq : nkv;
+        const float* src = pr + (isq ? oqp : okp);
+        float gx[8], gy[8], gz[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool ok = j0 + e < N;
+            const float x = ok ? src[(size_t)e * ldp + idx] : 0.f, y = ok ? src[(size_t)e * ldp + blk + idx] : 0.f;
+            const float zc = ok ? src[(size_t)e * ldp + 2 * blk + idx] : 0.f;
+            const float* R = sR[e];
+            gx[e] = ok ? R[0] * x + R[1] * y + R[2] * zc + R[9] : 0.f;
+            gy[e] = ok ? R[3] * x + R[4] * y + R[5] * zc + R[10] : 0.f;
+            gz[e] = ok ? R[6] * x + R[7] * y + R[8] * zc + R[11] : 0.f;
+        }
+        if (isq) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (j0 + e < N) {
+                    float* d = qp + ((size_t)(b * N + j0 + e) * nq + idx) * 3;
+                    d[0] = gx[e]; d[1] = gy[e]; d[2] = gz[e];
+                }
+            }
+        } else {
+            const int hh = idx / (Pq + Pv), pp = idx % (Pq + Pv);
+            if (pp < Pq) {
+                float* d = kpT + ((((size_t)b * H + hh) * Pq + pp) * 3) * N + j0;
+                put8(d, gx); put8(d + N, gy); put8(d + 2 * N, gz);
+            } else {
+                const int w = (pp - Pq) * 3;
+                put_frag(hh, 1 + (w >> 4), w & 15, gx);
+                put_frag(hh, 1 + ((w + 1) >> 4), (w + 1) & 15, gy);
+                put_frag(hh, 1 + ((w + 2) >> 4), (w + 2) & 15, gz);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) mp = fmaxf(mp, fmaxf(fabsf(gx[e]), fmaxf(fabsf(gy[e]), fabsf(gz[e]))));
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mv = fmaxf(mv, __shfl_xor(mv, o)); mp = fmaxf(mp, __shfl_xor(mp, o)); }
+    if ((threadIdx.x & 63) == 0) { atomicMax(&smax[0], __float_as_uint(mv)); atomicMax(&smax[1], __float_as_uint(mp)); }
+    __syncthreads();
+    if (threadIdx.x < 2) vmax[((size_t)b * G + grp) * 2 + threadIdx.x] = __uint_as_float(smax[threadIdx.x]);
+}
+
+
 // ---------------------------------------------------------------------------
 // IPA attention core, one work-group per query residue (b, i)
 // (modules/invariant_point_attention.py:181-249):
@@ -1154,17 +1253,19 @@ __global__ __launch_bounds__(MF ? 128 * Q : 512, MF ? 4 : 1) void k_ipa_attn_q(c
                                                     const float* __restrict__ rots, const float* __restrict__ trans,
                                                     const float* __restrict__ rmask, const float* __restrict__ head_w,
                                                     float* __restrict__ cat, int B, int N, int layer, int rev,
-                                                    const unsigned* __restrict__ pmax, unsigned long long* ts, int b0) {
-    // NT threads: 512 (Q = 4), or 1024 with the matrix-pipe o_pair and Q = 8 -- two waves per query there, and every K / V value
-    // fetched from L2 then serves eight queries: the logits and o / o_pt phases are bound by the CU's L2 read path (~35 B/clk)
-    constexpr int NT = MF ? 128 * Q : 512;
+                                                    const unsigned* __restrict__ pmax, unsigned long long* ts, int b0,
+                                                    const float* __restrict__ vf, const float* __restrict__ vmax) {
+    constexpr int NT = MF ? 128 * Q : 512;       // 512 threads (Q = 4), or 1024 with Q = 8: two waves per query in o_pair, and every key / value
+                                                 // fetched through the L1 then serves eight queries
     constexpr int CP = 128, HC = H * C, NQP = H * PQ * 3, NPT = H * PV * 3, NCAT = HC + H * PV * 4 + H * CP, HH = H / (NT / 256);
-    static_assert(H % (NT / 256) == 0 && C % 4 == 0 && HC + NPT <= 512 && (NT == 512 || NT == 1024), "shape");
+    static_assert(H % (NT / 256) == 0 && C % 4 == 0 && HC + NPT <= 512, "shape");
     static_assert(!MF || H <= 16, "matrix-pipe o_pair: 2 Q waves = Q queries x 2 channel halves");
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int NP8 = (N + 7) & ~7;
-    float* att = sm;                            // [Q][H][NP8], zero padded
-    float* sq = att + Q * H * NP8;              // [Q][HC]
+    const int NPA = NP8 + 4;                    // row stride of att: rows 1 KiB apart (N = 256) would put the 16 rows of a matrix-pipe A
+                                                // fragment (one b128 read per lane) in the same banks
+    float* att = sm;                            // [Q][H][NPA], zero padded up to NP8
+    float* sq = att + Q * H * NPA;              // [Q][HC]
     float* sqp = sq + Q * HC;                   // [Q][NQP]
     float* shw = sqp + Q * NQP;                 // [H] (16 reserved)
     float* opt = shw + 16;                      // [Q][NPT]
@@ -1232,7 +1333,7 @@ __global__ __launch_bounds__(MF ? 128 * Q : 512, MF ? 4 : 1) void k_ipa_attn_q(c
                     }
                     a += pt * (-0.5f);
                     a += sqm[q];
-                    att[(q * H + hh) * NP8 + j] = (j < N) ? a : -3.0e38f;
+                    att[(q * H + hh) * NPA + j] = (j < N) ? a : -3.0e38f;
                 }
             }
         }
@@ -1248,7 +1349,7 @@ __global__ __launch_bounds__(MF ? 128 * Q : 512, MF ? 4 : 1) void k_ipa_attn_q(c
         };
         const int l16 = lane & 15;
         for (int rr = wave * 4 + (lane >> 4); rr < Q * H; rr += NT / 16) {
-            float* ar = att + rr * NP8;
+            float* ar = att + rr * NPA;
             float mx = -3.0e38f;
             for (int j = 4 * l16; j < NP8; j += 64) {
                 const float4 v = *reinterpret_cast<const float4*>(ar + j);
@@ -1274,32 +1375,119 @@ __global__ __launch_bounds__(MF ? 128 * Q : 512, MF ? 4 : 1) void k_ipa_attn_q(c
     }
     __syncthreads();
     stamp();
-    // o and o_pt: one output column per thread, Q accumulators, j unrolled x8.  With 1024 threads the two halves of the
-    // work-group take the two halves of the j range (the loop is a chain of L2 round trips: twice the loads in flight) and
-    // leave their partial sums in LDS; they are added where they are consumed, after the barrier that follows o_pair.
-    constexpr int PARTS = NT / 512;
-    float* osum = opt + Q * NPT;                // [PARTS][Q][HC + NPT]   (PARTS = 2 only)
-    if ((tid & 511) < HC + NPT) {
-        const int part = tid >> 9, col = tid & 511;
+    // o and o_pt.  MF: on the matrix pipe -- per head one 16 x 16 x 32 tile per column block (16 channels of v, 24 point coordinates in two
+    // blocks) and 32 keys: A = the attention rows of the Q queries (rows Q.. are zero), split under the scale 2^14; B = the f32
+    // fragments k_ipa_prep left, split here under one scale per structure for v and one for the points (largest magnitude to
+    // [2^13, 2^14)).  Wave w takes heads 3 (w >> 1) .. + 2 and the key half w & 1; the two partial sums per output meet in LDS
+    // (osum) after o_pair.  As a per-thread dot product (below, MF = 0) this phase was the kernel's second largest: 2.5 k vector
+    // instructions per thread.
+    // Wave layout: Q = 4 (8 waves) -- heads 3 (w >> 1) .. + 2 and the key half w & 1, the two partial sums per output meet in LDS (osum)
+    // after o_pair; Q = 8 (16 waves) -- wave w < 12 takes head w over all keys and writes its results itself.
+    constexpr int JP = MF ? (NT / 64 >= H ? 1 : 2) : 1;      // key parts
+    constexpr int PARTS = JP;
+    float* osum = opt + Q * NPT;                // [JP][Q][HC + NPT]   (JP = 2 only)
+    if constexpr (MF) {
+        static_assert(Q <= 16 && Q % 4 == 0 && C == 16 && PV * 3 <= 32 && (JP == 1 || ((NT / 64) % JP == 0 && H % (NT / 64 / JP) == 0)), "matrix-pipe o / o_pt");
+        constexpr int HG = JP == 1 ? H : NT / 64 / JP, HL = H / HG, NBK = 1 + (PV * 3 + 15) / 16;
+        const int KS = (N + 31) >> 5, ksm = (KS + JP - 1) / JP;
+        const int hg = wave / JP, jh = wave % JP, m = lane & 15, g = lane >> 4;
+        const int ks0 = jh * ksm, nks = hg < HG ? max(min(KS - ks0, ksm), 0) : 0, nit = nks * HL;
+        float mv = 0.f, mp = 0.f;                 // the structure's largest |v|, |v_pt|: every wave reduces k_ipa_prep_frag's group maxima itself
+        for (int j = lane; j < (N + 7) >> 3; j += 64) {
+            const float2 t = *reinterpret_cast<const float2*>(vmax + ((size_t)b * ((N + 7) >> 3) + j) * 2);
+            mv = fmaxf(mv, t.x); mp = fmaxf(mp, t.y);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mv = fmaxf(mv, __shfl_xor(mv, o)); mp = fmaxf(mp, __shfl_xor(mp, o)); }
+        const int exv = min(max((int)((__float_as_uint(mv) >> 23) & 0xff), 28), 254), exp_ = min(max((int)((__float_as_uint(mp) >> 23) & 0xff), 28), 254);
+        const float sv = __uint_as_float((unsigned)(267 - exv) << 23), sp = __uint_as_float((unsigned)(267 - exp_) << 23);
+        const float iv = __uint_as_float((unsigned)(exv - 27) << 23), ip = __uint_as_float((unsigned)(exp_ - 27) << 23);
+        const float sa = (m < Q) ? 16384.0f : 0.0f;
+        const float* ar = att + (size_t)min(m, Q - 1) * H * NPA + 8 * g;
+        const float* vb = vf + ((size_t)b * H * NBK * KS) * 512 + lane * 8;
+        // heads one after the other (12 accumulator registers), keys inside; the fragments of the next step are requested before this
+        // one is worked on.  (Two steps ahead was slower: 1 KiB per load instruction and 64 B / clk into the CU, the phase runs at
+        // three quarters of what the L1 can take -- its bytes, not their latency, are the limit.)
+        f32x4 acc[NBK];
+#pragma unroll
+        for (int c = 0; c < NBK; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float4 bb[2][NBK][2];
+        auto fetch = [&](int it, float4 (&dst)[NBK][2]) {
+            const int hh = hg * HL + it / nks, ks = ks0 + it % nks;
+#pragma unroll
+            for (int c = 0; c < NBK; ++c) {
+                const float* src = vb + (((size_t)hh * NBK + c) * KS + ks) * 512;
+                dst[c][0] = *reinterpret_cast<const float4*>(src);
+                dst[c][1] = *reinterpret_cast<const float4*>(src + 4);
+            }
+        };
+        auto step = [&](int it, float4 (&cur)[NBK][2], float4 (&nxt)[NBK][2]) {
+            if (it + 1 < nit) fetch(it + 1, nxt);
+            const int hh = hg * HL + it / nks, ki = it % nks, ks = ks0 + ki;
+            const bool live = ks * 32 + 8 * g < NP8;                              // att is zero padded up to NP8 only
+            const float* ap = ar + hh * NPA + (live ? ks * 32 : 0);
+            const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
+            const float xa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            h8 ah, al;
+            hx_split8(xa, live ? sa : 0.0f, ah, al);
+#pragma unroll
+            for (int c = 0; c < NBK; ++c) {
+                const float xb[8] = {cur[c][0].x, cur[c][0].y, cur[c][0].z, cur[c][0].w, cur[c][1].x, cur[c][1].y, cur[c][1].z, cur[c][1].w};
+                h8 bh, bl;
+                hx_split8(xb, c ? sp : sv, bh, bl);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[c], 0, 0, 0);
+            }
+            if (ki == nks - 1) {                                                  // the head is through
+#pragma unroll
+                for (int c = 0; c < NBK; ++c) {
+                    const int w = (c - 1) * 16 + m;                                // point coordinate of this lane in blocks 1..
+                    if (g < Q / 4 && (c == 0 || w < PV * 3)) {                     // D row 4 g + r = query, column m
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int q = 4 * g + r;
+                            const float val = acc[c][r] * (c ? ip : iv);
+                            if (JP > 1) osum[(jh * Q + q) * (HC + NPT) + (c == 0 ? hh * C + m : HC + hh * PV * 3 + w)] = val;
+                            else if (q < nq) {
+                                if (c == 0) cat[(size_t)(b * N + i0 + q) * NCAT + hh * C + m] = val;
+                                else opt[q * NPT + hh * PV * 3 + w] = val;
+                            }
+                        }
+                    }
+                    acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        };
+        if (nit > 0) fetch(0, bb[0]);
+        for (int it = 0; it < nit; it += 2) {
+            step(it, bb[0], bb[1]);
+            if (it + 1 < nit) step(it + 1, bb[1], bb[0]);
+        }
+        if (JP > 1 && nit == 0 && g == 0 && hg < HG) {                             // no keys in this part (N <= 32): its partial sums are zero
+            for (int hl = 0; hl < HL; ++hl)
+                for (int c = m; c < C + PV * 3; c += 16)
+                    for (int q = 0; q < Q; ++q) osum[(jh * Q + q) * (HC + NPT) + (c < C ? (hg * HL + hl) * C + c : HC + (hg * HL + hl) * PV * 3 + (c - C))] = 0.f;
+        }
+    } else if ((tid & 511) < HC + NPT) {
+        const int col = tid & 511;
         const bool isv = col < HC;
         const int w = isv ? col : col - HC;
         const int hh = isv ? (col / C) : (w / (PV * 3));
         const float* vv = isv ? v + (size_t)b * N * HC + col : vp + (size_t)b * N * NPT + w;
         const int ld = isv ? HC : NPT;
-        const int jmid = PARTS == 2 ? ((NP8 / 2 + 7) & ~7) : NP8;
-        const int jb = part ? jmid : 0, je = part ? NP8 : jmid;
         float acc[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) acc[q] = 0.f;
         // 16 rows of V in flight per thread (the loop is a chain of L2 round trips), then 8 at a time for the tail
-        int j0 = jb;
-        for (; j0 + 16 <= je; j0 += 16) {
+        int j0 = 0;
+        for (; j0 + 16 <= NP8; j0 += 16) {
             float x[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) x[k] = vv[(size_t)min(j0 + k, N - 1) * ld];
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
-                const float* ar = att + (q * H + hh) * NP8 + j0;
+                const float* ar = att + (q * H + hh) * NPA + j0;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const float4 a = *reinterpret_cast<const float4*>(ar + 4 * u);
@@ -1307,13 +1495,13 @@ __global__ __launch_bounds__(MF ? 128 * Q : 512, MF ? 4 : 1) void k_ipa_attn_q(c
                 }
             }
         }
-        for (; j0 < je; j0 += 8) {
+        for (; j0 < NP8; j0 += 8) {
             float x[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) x[k] = vv[(size_t)min(j0 + k, N - 1) * ld];
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
-                const float* ar = att + (q * H + hh) * NP8 + j0;
+                const float* ar = att + (q * H + hh) * NPA + j0;
                 const float4 a0 = *reinterpret_cast<const float4*>(ar), a1 = *reinterpret_cast<const float4*>(ar + 4);
                 acc[q] += a0.x * x[0]; acc[q] += a0.y * x[1]; acc[q] += a0.z * x[2]; acc[q] += a0.w * x[3];
                 acc[q] += a1.x * x[4]; acc[q] += a1.y * x[5]; acc[q] += a1.z * x[6]; acc[q] += a1.w * x[7];
@@ -1321,8 +1509,7 @@ __global__ __launch_bounds__(MF ? 128 * Q : 512, MF ? 4 : 1) void k_ipa_attn_q(c
         }
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-            if (PARTS == 2) osum[(part * Q + q) * (HC + NPT) + col] = acc[q];
-            else if (q < nq) {
+            if (q < nq) {
                 if (isv) cat[(size_t)(b * N + i0 + q) * NCAT + col] = acc[q];
                 else opt[q * NPT + w] = acc[q];
             }
@@ -1339,7 +1526,7 @@ __global__ __launch_bounds__(MF ? 128 * Q : 512, MF ? 4 : 1) void k_ipa_attn_q(c
             const float inv = __uint_as_float((unsigned)(ex - 27) << 23);          // 1 / (sp 2^14)
             const float sa = (m < H) ? 16384.0f : 0.0f;                            // rows 12..15 of the A tile are padding
             const float* zr = z + ((size_t)row * N) * CP + hc * 64 + m * 4;
-            const float* ar = att + (q * H + min(m, H - 1)) * NP8 + 8 * g;
+            const float* ar = att + (q * H + min(m, H - 1)) * NPA + 8 * g;
             f32x4 acc[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1394,14 +1581,14 @@ __global__ __launch_bounds__(MF ? 128 * Q : 512, MF ? 4 : 1) void k_ipa_attn_q(c
 #pragma unroll
         for (int hh = 0; hh < H; ++hh) acc[hh] = make_float4(0.f, 0.f, 0.f, 0.f);
         const float* zr = z + ((size_t)row * N) * CP + c4 * 4;
-        const float* aq = att + q * H * NP8;
+        const float* aq = att + q * H * NPA;
         for (int jb = jg * 8; jb < NP8; jb += 128) {        // 8 consecutive rows per thread: attention weights as two b128 reads
             float4 zz[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) zz[k] = *reinterpret_cast<const float4*>(zr + (size_t)min(jb + k, N - 1) * CP);
 #pragma unroll
             for (int hh = 0; hh < H; ++hh) {
-                const float4 a0 = *reinterpret_cast<const float4*>(aq + hh * NP8 + jb), a1 = *reinterpret_cast<const float4*>(aq + hh * NP8 + jb + 4);
+                const float4 a0 = *reinterpret_cast<const float4*>(aq + hh * NPA + jb), a1 = *reinterpret_cast<const float4*>(aq + hh * NPA + jb + 4);
                 const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};     // zero for j >= N (padding)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -1582,11 +1769,17 @@ void launch_layernorm_rows(genie_ctx* h, hipStream_t st, const float* in, float*
     hipLaunchKernelGGL(k_layernorm_rows, dim3((M + 3) / 4), dim3(256), 0, st, in, out, M, C, g, b);
 }
 
+static bool ipa_attn_mfma_av(const genie_ctx* h);      // the attention kernel in use wants V / v_pts as fragments
 void launch_ipa_prep(genie_ctx* h, hipStream_t st, int b0, int nb) {
     ProfScope ps(h, st, KC_IPA_PREP);
     const genie_dims_t& d = h->d;
     if (nb < 0) { b0 = 0; nb = h->B; }
     const int ldp = d.n_head_ipa * (3 * d.c_hidden_ipa + 3 * d.n_qk_point + 3 * (d.n_qk_point + d.n_v_point));
+    if (ipa_attn_mfma_av(h)) {
+        hipLaunchKernelGGL(k_ipa_prep_frag, dim3(nb * ((h->N + 7) / 8)), dim3(256), 0, st, h->proj, ldp, h->rots_w, h->trans_w, h->kT, h->qp,
+                           h->kpT, h->vf, h->vmax, h->N, d.n_head_ipa, d.c_hidden_ipa, d.n_qk_point, d.n_v_point, b0);
+        return;
+    }
     hipLaunchKernelGGL(k_ipa_prep, dim3(nb * h->N), dim3(256), 0, st, h->proj, ldp, h->rots_w, h->trans_w, h->kT, h->v, h->qp,
                        h->kpT, h->vp, h->N, d.n_head_ipa, d.c_hidden_ipa, d.n_qk_point, d.n_v_point, b0 * h->N);
 }
@@ -1600,20 +1793,28 @@ static size_t ipa_attn_t1_lds(const genie_dims_t& d, int N) {      // k_ipa_attn
 }
 #define IPA_Q8 8             // queries per work-group of the 1024-thread matrix-pipe form
 static size_t ipa_attn_q_lds(const genie_dims_t& d, int N, bool mf = false, int Q = IPA_Q);
+static bool ipa_use_q8(const genie_dims_t& d, int N) {
+    static const bool on = getenv("GENIE_IPA_Q8") != nullptr;       // measured slower (80.5 vs 76.0 us per launch): opt-in
+    return on && ipa_attn_q_lds(d, N, true, IPA_Q8) <= 160 * 1024;
+}
 static bool ipa_use_q(const genie_dims_t& d, int N) { return ipa_attn_q_lds(d, N) <= 160 * 1024; }
-static bool ipa_use_q8(const genie_dims_t& d, int N) { return ipa_attn_q_lds(d, N, true, IPA_Q8) <= 160 * 1024 && getenv("GENIE_IPA_Q8"); }
 static size_t ipa_attn_t_lds(const genie_dims_t& d, int N) { return ipa_use_q(d, N) ? ipa_attn_q_lds(d, N) : ipa_attn_t1_lds(d, N); }
 static size_t ipa_attn_q_lds(const genie_dims_t& d, int N, bool mf, int Q) {   // k_ipa_attn_q<12, 16, 4, 8, Q, mf>: no reduction buffer with mf
     const size_t H = d.n_head_ipa;
-    return ((size_t)Q * H * ((N + 7) & ~7) + Q * H * d.c_hidden_ipa + Q * H * d.n_qk_point * 3 + 16 +
+    return ((size_t)Q * H * (((N + 7) & ~7) + 4) + Q * H * d.c_hidden_ipa + Q * H * d.n_qk_point * 3 + 16 +
             Q * H * d.n_v_point * 3 + (mf ? 0 : 4 * H * d.c_p) +
-            (mf && Q == IPA_Q8 ? 2 * Q * H * (d.c_hidden_ipa + 3 * d.n_v_point) : 0)) * sizeof(float);
+            (mf && Q == IPA_Q ? 2 * Q * H * (d.c_hidden_ipa + 3 * d.n_v_point) : 0)) * sizeof(float);       // mf, Q = 4: the two key halves' partial o / o_pt
 }
 size_t ipa_attn_lds(const genie_dims_t& d, int N) {
     if (ipa_is_base(d)) return ipa_attn_t_lds(d, N);
     return ((size_t)d.n_head_ipa * N + 8 * d.n_head_ipa * d.c_p + d.n_head_ipa * d.n_v_point * 3) * sizeof(float);
 }
 
+// hx arithmetic: a v and a v_pts run on the matrix pipe, from the fragment layout k_ipa_prep writes for it
+static bool ipa_attn_mfma_av(const genie_ctx* h) { return h->hx && ipa_is_base(h->d) && ipa_use_q(h->d, h->N); }
+size_t ipa_vf_floats(const genie_dims_t& d, int B, int N) {
+    return ipa_is_base(d) ? (size_t)B * d.n_head_ipa * (1 + (3 * d.n_v_point + 15) / 16) * ((N + 31) / 32) * 512 : 64;
+}
 // the four-query kernel takes a batch range (the two halves of a batch run their structure layers on two streams)
 bool ipa_attn_splits(const genie_ctx* h) { return ipa_is_base(h->d) && ipa_use_q(h->d, h->N); }
 void launch_ipa_attn(genie_ctx* h, hipStream_t st, int layer, const float* head_w, int b0, int nb) {
@@ -1635,15 +1836,15 @@ void launch_ipa_attn(genie_ctx* h, hipStream_t st, int layer, const float* head_
         if (h->hx && ipa_use_q8(d, h->N))
             hipLaunchKernelGGL((k_ipa_attn_q<12, 16, 4, 8, IPA_Q8, 1>), dim3(nb * ((h->N + IPA_Q8 - 1) / IPA_Q8)), dim3(1024),
                                ipa_attn_q_lds(d, h->N, true, IPA_Q8), st, h->proj, ldp, h->kT, h->v, h->qp, h->kpT, h->vp, h->ipa_bias, h->p,
-                               h->rots_w, h->trans_w, h->rmaskf, head_w, h->cat, h->B, h->N, layer, rev, h->pmax, ts, b0);
+                               h->rots_w, h->trans_w, h->rmaskf, head_w, h->cat, h->B, h->N, layer, rev, h->pmax, ts, b0, h->vf, h->vmax);
         else if (h->hx)
             hipLaunchKernelGGL((k_ipa_attn_q<12, 16, 4, 8, IPA_Q, 1>), grid, dim3(512), ipa_attn_q_lds(d, h->N, true), st, h->proj, ldp,
                                h->kT, h->v, h->qp, h->kpT, h->vp, h->ipa_bias, h->p, h->rots_w, h->trans_w, h->rmaskf, head_w, h->cat,
-                               h->B, h->N, layer, rev, h->pmax, ts, b0);
+                               h->B, h->N, layer, rev, h->pmax, ts, b0, h->vf, h->vmax);
         else
             hipLaunchKernelGGL((k_ipa_attn_q<12, 16, 4, 8, IPA_Q, 0>), grid, dim3(512), ipa_attn_q_lds(d, h->N), st, h->proj, ldp,
                                h->kT, h->v, h->qp, h->kpT, h->vp, h->ipa_bias, h->p, h->rots_w, h->trans_w, h->rmaskf, head_w, h->cat,
-                               h->B, h->N, layer, rev, h->pmax, ts, b0);
+                               h->B, h->N, layer, rev, h->pmax, ts, b0, nullptr, nullptr);
         if (ts) {
             unsigned long long v[24] = {0};
             (void)hipStreamSynchronize(st);
@@ -1773,9 +1974,8 @@ void single_kernels_init(const genie_dims_t& d, int n_max) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipa_attn_q_lds(d, n_max));
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn_q<12, 16, 4, 8, IPA_Q, 1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipa_attn_q_lds(d, n_max, true));
-            if (ipa_use_q8(d, n_max))
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn_q<12, 16, 4, 8, IPA_Q8, 1>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipa_attn_q_lds(d, n_max, true, IPA_Q8));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn_q<12, 16, 4, 8, IPA_Q8, 1>),       // (used up to the N that fits)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>(ipa_attn_q_lds(d, n_max, true, IPA_Q8), 160 * 1024));
         } else
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ipa_attn_t<12, 16, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)ipa_attn_t1_lds(d, n_max));
