@@ -154,9 +154,16 @@ struct Run {
     }
     // Y[R][O] = (xhat gamma + beta) W^T + b without forming xhat gamma + beta: the Linear's weights folded with the LayerNorm's affine
     // (`fold`: O K + O floats written by launch_fold_ln_table at the start of the pass) applied to xhat
-    void lin_fwd_ln(const float* Xhat, long long R, int K, int O, float* Y, const float* fold, bool relu = false) {
-        GemmP p{Xhat, fold, Y, fold ? fold + (size_t)O * K : nullptr, (int)R, O, K, K, 1, 1, K, O, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0f, 0};
+    void lin_fwd_ln(const float* Xhat, long long R, int K, int O, float* Y, const float* fold, bool relu = false, const float* fold_b = nullptr) {
+        GemmP p{Xhat, fold, Y, fold_b ? fold_b : fold ? fold + (size_t)O * K : nullptr, (int)R, O, K, K, 1, 1, K, O, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0f, 0};
         p.relu = relu ? 1 : 0;
+        gemm(p);
+    }
+    // ... `nb` of them on the same xhat in one GEMM (xhat is read once): folded weights stacked [nb O][K], biases [nb O]; result k to Y[k]
+    void lin_fwd_ln_cat(const float* Xhat, long long R, int K, int O, int nb, float* const* Y, const float* fold, const float* fold_b) {
+        GemmP p{Xhat, fold, Y[0], fold_b, (int)R, nb * O, K, K, 1, 1, K, O, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0f, 0};
+        p.cblk = O; p.cblk_m = 0;
+        for (int k = 0; k < nb; ++k) p.ctab[k] = Y[k] - Y[0];
         gemm(p);
     }
     // dW[O][K] += dY^T (xhat gamma + beta) without forming xhat gamma + beta:  gamma[k] (dY^T xhat)[o][k]  +  beta[k] db[o]
@@ -171,6 +178,21 @@ struct Run {
         if (dry) return;
         ProfScope ps_(h, st, KC_TR_EW);
         launch_rank1_add(st, G + w, W + beta_off, G + b_off, O, K);
+    }
+    // ... of `nb` Linears of O outputs each on the same xhat, their output gradients the column blocks of dYcat [R][nb O]: one GEMM
+    // (xhat is read once), its row blocks landing on the nb weight gradients inside the blob
+    void lin_bwd_w_ln_cat(const float* dYcat, long long R, int O, int nb, const float* Xhat, int K, const size_t* w, const size_t* b_off, size_t g_off,
+                          size_t beta_off) {
+        if (!G) return;
+        GemmP p{dYcat, Xhat, G, nullptr, nb * O, K, (int)R, 1, (long long)nb * O, K, 1, K, 1, 1, 1, 0, 0, 0, 0, 0, 0, gemm_splits((long long)nb * O, K, R, 1), 1.0f, 2};
+        p.asum = G;
+        p.colscale = W + g_off;
+        p.cblk = O; p.cblk_m = 1;
+        for (int k = 0; k < nb; ++k) { p.ctab[k] = (long long)w[k]; p.atab[k] = (long long)b_off[k]; }
+        gemm(p);
+        if (dry) return;
+        ProfScope ps_(h, st, KC_TR_EW);
+        for (int k = 0; k < nb; ++k) launch_rank1_add(st, G + w[k], W + beta_off, G + b_off[k], O, K);
     }
     void ln_fwd(const float* x, size_t g, size_t b, float* y, float* xhat, float* rstd, long long R, int C) {
         if (dry) return;
@@ -251,19 +273,36 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
     std::vector<size_t> fold_tri((size_t)L * 2 * 6), fold_tr(L);
     size_t fold_floats = 0;
     {
+        // (folded weights [O][K] at the returned offset, the folded bias right behind them)
         auto plan = [&](size_t w, size_t b, size_t g, size_t be, int Oo, int Kk) {
-            fold_plan.push_back(FoldEntry{(long long)w, (long long)b, (long long)g, (long long)be, (long long)fold_floats, Oo, Kk});
+            fold_plan.push_back(FoldEntry{(long long)w, (long long)b, (long long)g, (long long)be, (long long)fold_floats,
+                                          (long long)(fold_floats + (size_t)Oo * Kk), Oo, Kk});
             const size_t at = fold_floats;
             fold_floats += ((size_t)Oo * Kk + Oo + 63) / 64 * 64;
             return at;
+        };
+        // five Linears on the same input whose folded weights form ONE matrix [5 O][K] (then the five biases): they run as one GEMM
+        auto plan5 = [&](const size_t (&w)[5], const size_t (&b)[5], size_t g, size_t be, int Oo, int Kk, size_t* f) {
+            for (int k = 0; k < 5; ++k) {
+                f[k] = fold_floats + (size_t)k * Oo * Kk;
+                fold_plan.push_back(FoldEntry{(long long)w[k], (long long)b[k], (long long)g, (long long)be, (long long)f[k],
+                                              (long long)(fold_floats + (size_t)5 * Oo * Kk + (size_t)k * Oo), Oo, Kk});
+            }
+            fold_floats += ((size_t)5 * Oo * Kk + 5 * Oo + 63) / 64 * 64;
         };
         for (int l = 0; l < L; ++l) {
             for (int dir = 0; dir < 2; ++dir) {
                 const TriOff& t = dir == 0 ? O.pair[l].out : O.pair[l].in;
                 size_t* f = &fold_tri[((size_t)l * 2 + dir) * 6];
-                f[0] = plan(t.ap_w, t.ap_b, t.lni_g, t.lni_b, ch, cp); f[1] = plan(t.ag_w, t.ag_b, t.lni_g, t.lni_b, ch, cp);
-                f[2] = plan(t.bp_w, t.bp_b, t.lni_g, t.lni_b, ch, cp); f[3] = plan(t.bg_w, t.bg_b, t.lni_g, t.lni_b, ch, cp);
-                f[4] = plan(t.g_w, t.g_b, t.lni_g, t.lni_b, cp, cp); f[5] = plan(t.z_w, t.z_b, t.lno_g, t.lno_b, cp, ch);
+                if (ch == cp) {
+                    const size_t w5[5] = {t.ap_w, t.ag_w, t.bp_w, t.bg_w, t.g_w}, b5[5] = {t.ap_b, t.ag_b, t.bp_b, t.bg_b, t.g_b};
+                    plan5(w5, b5, t.lni_g, t.lni_b, ch, cp, f);
+                } else {
+                    f[0] = plan(t.ap_w, t.ap_b, t.lni_g, t.lni_b, ch, cp); f[1] = plan(t.ag_w, t.ag_b, t.lni_g, t.lni_b, ch, cp);
+                    f[2] = plan(t.bp_w, t.bp_b, t.lni_g, t.lni_b, ch, cp); f[3] = plan(t.bg_w, t.bg_b, t.lni_g, t.lni_b, ch, cp);
+                    f[4] = plan(t.g_w, t.g_b, t.lni_g, t.lni_b, cp, cp);
+                }
+                f[5] = plan(t.z_w, t.z_b, t.lno_g, t.lno_b, cp, ch);
             }
             fold_tr[l] = plan(O.pair[l].w1, O.pair[l].b1, O.pair[l].ln_g, O.pair[l].ln_b, nh, cp);
         }
@@ -292,10 +331,16 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         if (cmf) { s.ap = T.f(P * ch); s.bp = T.f(P * ch); }
         r.ln_fwd(z, t.lni_g, t.lni_b, nullptr, s.xhat, s.rstd, P, cp);                                  // (xhat only: the Linears below run on folded weights)
         auto fw = [&](int k) -> const float* { return dry ? nullptr : foldbuf + fo[k]; };
-        r.lin_fwd_ln(s.xhat, P, cp, ch, s.ap, fw(0));
-        r.lin_fwd_ln(s.xhat, P, cp, ch, s.ag, fw(1));
-        r.lin_fwd_ln(s.xhat, P, cp, ch, s.bp, fw(2));
-        r.lin_fwd_ln(s.xhat, P, cp, ch, s.bg, fw(3));
+        const bool cat5 = ch == cp;                 // the five Linears on xhat as one GEMM (fold_plan stacked their folded weights)
+        if (cat5) {
+            float* const Y5[5] = {s.ap, s.ag, s.bp, s.bg, s.g};
+            r.lin_fwd_ln_cat(s.xhat, P, cp, ch, 5, Y5, fw(0), dry ? nullptr : fw(0) + (size_t)5 * ch * cp);
+        } else {
+            r.lin_fwd_ln(s.xhat, P, cp, ch, s.ap, fw(0));
+            r.lin_fwd_ln(s.xhat, P, cp, ch, s.ag, fw(1));
+            r.lin_fwd_ln(s.xhat, P, cp, ch, s.bp, fw(2));
+            r.lin_fwd_ln(s.xhat, P, cp, ch, s.bg, fw(3));
+        }
         float *xcm, *xn;
         if (cmf) {
             if (!dry) { ProfScope ps_(h, st, KC_TR_TRANSPOSE); launch_gate_to_cm(st, s.ap, s.ag, s.bp, s.bg, rm, s.acm, s.bcm, B, N, ch); }
@@ -329,7 +374,7 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
             r.ln_fwd(xrm, t.lno_g, t.lno_b, nullptr, s.xhat_o, s.rstd_o, P, ch);
         }
         r.lin_fwd_ln(s.xhat_o, P, ch, cp, s.u, fw(5));
-        r.lin_fwd_ln(s.xhat, P, cp, cp, s.g, fw(4));
+        if (!cat5) r.lin_fwd_ln(s.xhat, P, cp, cp, s.g, fw(4));
         {
             float *u = s.u, *g = s.g;
             r.ew(P * cp, [=] __device__(long long e) {
@@ -566,11 +611,16 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
                     (void)hipMemcpyAsync(wcat + (size_t)k * ch * cp, Wd + offs[k], (size_t)(k < 4 ? ch : cp) * cp * 4, hipMemcpyDeviceToDevice, st);
             }
             dzn = T.f(P * cp);
-            r.lin_bwd_w_ln(dap, P, ch, sv.xhat, cp, t.ap_w, t.ap_b, t.lni_g, t.lni_b, ncat5);
-            r.lin_bwd_w_ln(dag, P, ch, sv.xhat, cp, t.ag_w, t.ag_b, t.lni_g, t.lni_b, ncat5);
-            r.lin_bwd_w_ln(dbp, P, ch, sv.xhat, cp, t.bp_w, t.bp_b, t.lni_g, t.lni_b, ncat5);
-            r.lin_bwd_w_ln(dbg, P, ch, sv.xhat, cp, t.bg_w, t.bg_b, t.lni_g, t.lni_b, ncat5);
-            r.lin_bwd_w_ln(dgl, P, cp, sv.xhat, cp, t.g_w, t.g_b, t.lni_g, t.lni_b, ncat5);
+            if (ch == cp) {
+                const size_t w5[5] = {t.ap_w, t.ag_w, t.bp_w, t.bg_w, t.g_w}, b5[5] = {t.ap_b, t.ag_b, t.bp_b, t.bg_b, t.g_b};
+                r.lin_bwd_w_ln_cat(dycat, P, ch, 5, sv.xhat, cp, w5, b5, t.lni_g, t.lni_b);
+            } else {
+                r.lin_bwd_w_ln(dap, P, ch, sv.xhat, cp, t.ap_w, t.ap_b, t.lni_g, t.lni_b, ncat5);
+                r.lin_bwd_w_ln(dag, P, ch, sv.xhat, cp, t.ag_w, t.ag_b, t.lni_g, t.lni_b, ncat5);
+                r.lin_bwd_w_ln(dbp, P, ch, sv.xhat, cp, t.bp_w, t.bp_b, t.lni_g, t.lni_b, ncat5);
+                r.lin_bwd_w_ln(dbg, P, ch, sv.xhat, cp, t.bg_w, t.bg_b, t.lni_g, t.lni_b, ncat5);
+                r.lin_bwd_w_ln(dgl, P, cp, sv.xhat, cp, t.g_w, t.g_b, t.lni_g, t.lni_b, ncat5);
+            }
             r.lin_bwd_x_ptr(dycat, P, ncat5, wcat, cp, dzn, cp);
         } else {
             float* darm = dxn; float* dbrm = T.f(P * ch);

@@ -18,6 +18,13 @@ struct GemmP {
                       // weight-gradient GEMM, which streams dY anyway
     const float* colscale;   // optional: the product's column n is scaled by colscale[n] before bias / accumulation -- a weight gradient
                              // taken against LayerNorm's xhat instead of xhat * gamma + beta (the beta part is launch_rank1_add's)
+    // optional: C as a row of separately placed blocks -- `cblk` output rows (cblk_m = 1) or columns (0) each, block t at C + ctab[t]
+    // (element (m, n) of the product at local index m - t cblk resp. n - t cblk inside it), its row sums at asum + atab[t].  Several
+    // Linears that share their input run as ONE GEMM this way although their results (forward: the projections; backward: the weight
+    // gradients inside the gradient blob) do not sit next to each other.  bias / colscale stay indexed by the product's column.
+    int cblk, cblk_m;
+    long long ctab[8], atab[8];
+    int xcd;          // set by launch_gemm: split-K work-groups renumbered so that the tiles of one K range share an XCD (its L2)
 };
 void launch_gemm(hipStream_t st, const GemmP& p, int terms);
 int gemm_splits(long long M, long long N, long long K, long long batch);
@@ -44,7 +51,7 @@ void launch_gate_bwd_from_cm(hipStream_t st, const float* dacm, const float* dbc
 //   Wf[o][k] = W[o][k] gamma[k],   bf[o] = b[o] + sum_k W[o][k] beta[k]          (b may be NULL)
 void launch_fold_ln(hipStream_t st, const float* W, const float* b, const float* gamma, const float* beta, float* Wf, float* bf, int O, int K);
 // ... for a table of Linears in one launch (all offsets into the weight blob `wts` / the scratch `dst`; b < 0: no bias)
-struct FoldEntry { long long w, b, g, beta, dst; int O, K; };
+struct FoldEntry { long long w, b, g, beta, dst, bdst; int O, K; };       // Wf at dst, bf at bdst
 void launch_fold_ln_table(hipStream_t st, const float* wts, float* dst, const FoldEntry* table_dev, int n_entries, int max_O);
 // dW[o][c] += beta[c] db[o]   (the beta part of a weight gradient taken against xhat, see GemmP::colscale)
 void launch_rank1_add(hipStream_t st, float* dW, const float* beta, const float* db, int O, int C);

@@ -255,8 +255,17 @@ __global__ __launch_bounds__(256, GM_WPS) void k_gemm_fast(const GemmP p) {
     __shared__ __attribute__((aligned(16))) __bf16 Bs[TERMS][64][GM_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
-    const int bz = blockIdx.z / p.nsplit, sp = blockIdx.z - bz * p.nsplit;
+    // p.xcd (split-K, batch 1, nsplit a multiple of 8): work-groups are handed to the eight XCDs round robin in launch order, so the
+    // tiles of ONE K range are renumbered onto ONE XCD -- the operand rows they share are then fetched into that XCD's L2 once, not
+    // into all eight
+    int bx = blockIdx.x, by = blockIdx.y, bzs = blockIdx.z;
+    if (p.xcd) {
+        const int tiles = gridDim.x * gridDim.y, id = bx + gridDim.x * (by + gridDim.y * bzs);
+        const int k = id >> 3, tile = k % tiles;
+        bzs = (k / tiles) * 8 + (id & 7); bx = tile % gridDim.x; by = tile / gridDim.x;
+    }
+    const int n0 = bx * 64, m0 = by * 64;
+    const int bz = bzs / p.nsplit, sp = bzs - bz * p.nsplit;
     const int z1 = bz / p.nb2, z2 = bz - z1 * p.nb2;
     const int ks = ((p.K + p.nsplit - 1) / p.nsplit + GM_BK - 1) / GM_BK * GM_BK;
     const int kbeg = sp * ks, kend = min(p.K, kbeg + ks);
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(256, GM_WPS) void k_gemm_fast(const GemmP p) {
     };
     f32x16 acc = zero16();
     const int nsteps = (kend - kbeg) / GM_BK;
-    const bool rowsum = !AKC && p.asum != nullptr && blockIdx.x == 0;     // uniform
+    const bool rowsum = !AKC && p.asum != nullptr && bx == 0;     // uniform
     float rs[4] = {0.f, 0.f, 0.f, 0.f};
     load();
     for (int it = 0; it < nsteps; ++it) {
@@ -329,12 +338,14 @@ __global__ __launch_bounds__(256, GM_WPS) void k_gemm_fast(const GemmP p) {
             for (int j = 0; j < 4; ++j) red[((tid >> 6) & 1) * 64 + 4 * mq + j] = rs[j];
         }
         __syncthreads();
-        if (tid < 64) atomicAdd(p.asum + m0 + tid, red[tid] + red[64 + tid]);
+        if (tid < 64) atomicAdd(p.asum + (p.cblk && p.cblk_m ? p.atab[m0 / p.cblk] - (long long)(m0 / p.cblk) * p.cblk : 0) + m0 + tid, red[tid] + red[64 + tid]);
     }
     const int col = n0 + wn * 32 + (lane & 31);
     const float bv = (p.bias && sp == 0) ? p.bias[col] : 0.f;
     const float al = p.colscale ? p.alpha * p.colscale[col] : p.alpha;
-    float* d0 = p.C + z1 * p.c1 + z2 * p.c2 + (long long)(m0 + wm * 32 + 4 * (lane >> 5)) * p.cm + (long long)col * p.cn;
+    long long cofs = 0;                          // C in blocks: the tile lies inside one (cblk is a multiple of the tile)
+    if (p.cblk) { const int t = (p.cblk_m ? m0 : n0) / p.cblk; cofs = p.ctab[t] - (long long)t * p.cblk * (p.cblk_m ? p.cm : p.cn); }
+    float* d0 = p.C + cofs + z1 * p.c1 + z2 * p.c2 + (long long)(m0 + wm * 32 + 4 * (lane >> 5)) * p.cm + (long long)col * p.cn;
     if (p.mode == 0) {
         const float* g0 = p.gate ? p.gate + (d0 - p.C) : nullptr;
 #pragma unroll
@@ -362,8 +373,17 @@ __global__ __launch_bounds__(512, 4) void k_gemm_big(const GemmP p) {
     __shared__ __attribute__((aligned(16))) __bf16 Bs[TERMS][128][GM_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int n0 = blockIdx.x * 128, m0 = blockIdx.y * 128;
-    const int bz = blockIdx.z / p.nsplit, sp = blockIdx.z - bz * p.nsplit;
+    // p.xcd (split-K, batch 1, nsplit a multiple of 8): work-groups are handed to the eight XCDs round robin in launch order, so the
+    // tiles of ONE K range are renumbered onto ONE XCD -- the operand rows they share are then fetched into that XCD's L2 once, not
+    // into all eight
+    int bx = blockIdx.x, by = blockIdx.y, bzs = blockIdx.z;
+    if (p.xcd) {
+        const int tiles = gridDim.x * gridDim.y, id = bx + gridDim.x * (by + gridDim.y * bzs);
+        const int k = id >> 3, tile = k % tiles;
+        bzs = (k / tiles) * 8 + (id & 7); bx = tile % gridDim.x; by = tile / gridDim.x;
+    }
+    const int n0 = bx * 128, m0 = by * 128;
+    const int bz = bzs / p.nsplit, sp = bzs - bz * p.nsplit;
     const int z1 = bz / p.nb2, z2 = bz - z1 * p.nb2;
     const int ks = ((p.K + p.nsplit - 1) / p.nsplit + GM_BK - 1) / GM_BK * GM_BK;
     const int kbeg = sp * ks, kend = min(p.K, kbeg + ks);
@@ -392,7 +412,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm_big(const GemmP p) {
     };
     f32x16 acc0 = zero16(), acc1 = zero16();
     const int nsteps = (kend - kbeg) / GM_BK;
-    const bool rowsum = !AKC && p.asum != nullptr && blockIdx.x == 0;     // uniform
+    const bool rowsum = !AKC && p.asum != nullptr && bx == 0;     // uniform
     float rs[4] = {0.f, 0.f, 0.f, 0.f};
     load();
     for (int it = 0; it < nsteps; ++it) {
@@ -445,9 +465,11 @@ __global__ __launch_bounds__(512, 4) void k_gemm_big(const GemmP p) {
             for (int j = 0; j < 4; ++j) red[((tid >> 6) & 1) * 128 + 4 * mq + j] = rs[j];
         }
         __syncthreads();
-        if (tid < 128) atomicAdd(p.asum + m0 + tid, red[tid] + red[128 + tid]);
+        if (tid < 128) atomicAdd(p.asum + (p.cblk && p.cblk_m ? p.atab[m0 / p.cblk] - (long long)(m0 / p.cblk) * p.cblk : 0) + m0 + tid, red[tid] + red[128 + tid]);
     }
-    float* dbase = p.C + z1 * p.c1 + z2 * p.c2 + (long long)(m0 + wm * 32 + 4 * (lane >> 5)) * p.cm;
+    long long cofs = 0;                          // C in blocks: the tile lies inside one (cblk is a multiple of the tile)
+    if (p.cblk) { const int t = (p.cblk_m ? m0 : n0) / p.cblk; cofs = p.ctab[t] - (long long)t * p.cblk * (p.cblk_m ? p.cm : p.cn); }
+    float* dbase = p.C + cofs + z1 * p.c1 + z2 * p.c2 + (long long)(m0 + wm * 32 + 4 * (lane >> 5)) * p.cm;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const f32x16& acc = half ? acc1 : acc0;
@@ -506,8 +528,27 @@ void launch_gemm(hipStream_t st, const GemmP& p_in, int terms) {
         const long long ks = ((p.K + p.nsplit - 1) / p.nsplit + GM_BK - 1) / GM_BK * GM_BK;
         const long long lim = 1LL << 24;              // a lane offset is at most 64 rows (or GM_BK k) of such a stride
         static const bool off = getenv("GENIE_GEMM_GENERIC") != nullptr;
-        if (!off && ua && ub && p.M % 64 == 0 && p.N % 64 == 0 && p.K % GM_BK == 0 && ks % GM_BK == 0 && p.am < lim && p.ak < lim && p.bk < lim &&
-            p.bn < lim && (long long)p.batch * p.nsplit < 65536 && p.M / 64 < 65536) {
+        const bool fast = !off && ua && ub && p.M % 64 == 0 && p.N % 64 == 0 && p.K % GM_BK == 0 && ks % GM_BK == 0 && p.am < lim && p.ak < lim && p.bk < lim &&
+                          p.bn < lim && (long long)p.batch * p.nsplit < 65536 && p.M / 64 < 65536;
+        if (p.cblk > 0 && !(fast && p.cblk % 128 == 0 && !p.gate && p.batch == 1)) {
+            // C in blocks is a property of the two tiled kernels: otherwise one GEMM per block
+            const int nblk = ((p.cblk_m ? p.M : p.N) + p.cblk - 1) / p.cblk;
+            for (int t = 0; t < nblk; ++t) {
+                GemmP q = p;
+                q.cblk = 0;
+                q.C = p.C + p.ctab[t];
+                const int w = std::min(p.cblk, (p.cblk_m ? p.M : p.N) - t * p.cblk);
+                if (p.cblk_m) { q.M = w; q.A = p.A + (long long)t * p.cblk * p.am; if (p.asum) q.asum = p.asum + p.atab[t]; }
+                else { q.N = w; q.B = p.B + (long long)t * p.cblk * p.bn; if (p.bias) q.bias = p.bias + (long long)t * p.cblk;
+                       if (p.colscale) q.colscale = p.colscale + (long long)t * p.cblk; }
+                if (q.mode == 2) q.nsplit = gemm_splits(q.M, q.N, q.K, q.batch);
+                launch_gemm(st, q, terms);
+            }
+            return;
+        }
+        if (fast) {
+            static const bool noxcd = getenv("GENIE_GEMM_NO_XCD") != nullptr;
+            p.xcd = (!noxcd && p.batch == 1 && p.nsplit >= 8 && p.nsplit % 8 == 0) ? 1 : 0;
             const bool akc = p.ak == 1, bkc = p.bk == 1;
             if (p.asum && (akc || p.batch != 1)) { launch_colsum(st, p.A, nullptr, p.K, p.M, p.asum, nullptr, p.ak); p.asum = nullptr; }
             static const bool nobig = getenv("GENIE_GEMM_NO_BIG") != nullptr;
@@ -550,6 +591,7 @@ int gemm_splits(long long M, long long N, long long K, long long batch) {
     const long long smax = (K + 127) / 128;
     if (s > smax) s = smax;
     if (s > 512) s = 512;
+    if (s >= 8 && batch == 1) s = std::min((s + 7) / 8 * 8, smax / 8 * 8 > 0 ? smax / 8 * 8 : s);      // a multiple of 8: one K range per XCD (GemmP::xcd)
     return (int)(s < 1 ? 1 : s);
 }
 
@@ -645,6 +687,63 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, co
         atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
     }
 }
+// ... C = 128 (every LayerNorm of the pair stack): a row is one half-wave of float4 lanes, eight rows per wave and iteration (the generic
+// form above has 2 KB per wave in flight and ran at 2.5 TB/s); gamma / beta sums in registers over the block's rows, one atomic per
+// column and block
+__global__ __launch_bounds__(256) void k_ln_bwd128(const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ rstd,
+                                                   const float* __restrict__ g, float* __restrict__ dx, long long R, int accumulate,
+                                                   int rows_per_block, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    constexpr int C = 128, U = 4;
+    __shared__ float red[2][8][C];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l32 = lane & 31, hw = lane >> 5;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+    const float4 gv = *reinterpret_cast<const float4*>(g + 4 * l32);
+    float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag;
+    for (long long rb = r0 + wave * 2 * U; rb < r1; rb += 8 * U) {
+        float4 d[U], xh[U], old[U];
+        float rs[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long row = rb + 2 * u + hw;
+            const bool ok = row < r1;
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            d[u] = ok ? *reinterpret_cast<const float4*>(dy + row * C + 4 * l32) : z4;
+            xh[u] = ok ? *reinterpret_cast<const float4*>(xhat + row * C + 4 * l32) : z4;
+            old[u] = (ok && accumulate) ? *reinterpret_cast<const float4*>(dx + row * C + 4 * l32) : z4;
+            rs[u] = ok ? rstd[row] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long row = rb + 2 * u + hw;
+            ag.x += d[u].x * xh[u].x; ag.y += d[u].y * xh[u].y; ag.z += d[u].z * xh[u].z; ag.w += d[u].w * xh[u].w;
+            ab.x += d[u].x; ab.y += d[u].y; ab.z += d[u].z; ab.w += d[u].w;
+            const float4 t = make_float4(d[u].x * gv.x, d[u].y * gv.y, d[u].z * gv.z, d[u].w * gv.w);
+            float s1 = (t.x + t.y) + (t.z + t.w), s2 = (t.x * xh[u].x + t.y * xh[u].y) + (t.z * xh[u].z + t.w * xh[u].w);
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            const float m1 = s1 * (1.0f / C), m2 = s2 * (1.0f / C);
+            if (row < r1) {
+                float4 v = make_float4(rs[u] * (t.x - m1 - xh[u].x * m2), rs[u] * (t.y - m1 - xh[u].y * m2), rs[u] * (t.z - m1 - xh[u].z * m2),
+                                       rs[u] * (t.w - m1 - xh[u].w * m2));
+                v.x += old[u].x; v.y += old[u].y; v.z += old[u].z; v.w += old[u].w;
+                *reinterpret_cast<float4*>(dx + row * C + 4 * l32) = v;
+            }
+        }
+    }
+    if (!dgamma) return;                                    // uniform
+    const int slot = wave * 2 + hw;
+    *reinterpret_cast<float4*>(&red[0][slot][4 * l32]) = ag;
+    *reinterpret_cast<float4*>(&red[1][slot][4 * l32]) = ab;
+    __syncthreads();
+    {
+        const int which = threadIdx.x >> 7, c = threadIdx.x & 127;
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a += red[which][k][c];
+        atomicAdd((which ? dbeta : dgamma) + c, a);
+    }
+}
 // column sums over rows: out_b[c] += sum_r a[r,c];  out_g[c] += sum_r a[r,c] w[r,c]   (LayerNorm gamma / beta and Linear bias gradients)
 // 256 threads = (256 / C) row groups x C columns (C < 256), or one row group looping over the columns; rows of a block are summed
 // in registers, row groups through LDS, blocks with one atomic per column.
@@ -690,6 +789,11 @@ void launch_ln_bwd(hipStream_t st, const float* dy, const float* xhat, const flo
                    float* dgamma, float* dbeta) {
     int rpb = (int)((R + 1023) / 1024);                     // about 1024 blocks; a multiple of eight rows each
     rpb = (rpb + 7) / 8 * 8;
+    if (C == 128 && R >= 4096) {
+        rpb = (rpb + 31) / 32 * 32;
+        hipLaunchKernelGGL(k_ln_bwd128, dim3((unsigned)((R + rpb - 1) / rpb)), dim3(256), 0, st, dy, xhat, rstd, g, dx, R, accumulate, rpb, dgamma, dbeta);
+        return;
+    }
     hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)((R + rpb - 1) / rpb)), dim3(256), 0, st, dy, xhat, rstd, g, dx, R, C, accumulate, rpb, dgamma, dbeta);
 }
 void launch_colsum(hipStream_t st, const float* a, const float* w, long long R, int C, float* out_b, float* out_g, long long lda) {
