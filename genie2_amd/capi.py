@@ -46,7 +46,8 @@ class GenieTaps(C.Structure):
 class GenieGemmDesc(C.Structure):
     """genie_gemm_desc_t (include/genie_hip.h): one strided, batched GEMM of the training path."""
     _fields_ = [(n, C.c_int32) for n in ('M', 'N', 'K', 'batch', 'nb2', 'nsplit', 'mode', 'terms', 'relu')] + \
-               [(n, C.c_int64) for n in ('am', 'ak', 'bk', 'bn', 'cm', 'cn', 'a1', 'a2', 'b1', 'b2', 'c1', 'c2')] + [('alpha', C.c_float)]
+               [(n, C.c_int64) for n in ('am', 'ak', 'bk', 'bn', 'cm', 'cn', 'a1', 'a2', 'b1', 'b2', 'c1', 'c2')] + [('alpha', C.c_float)] + \
+               [('cblk', C.c_int32), ('cblk_m', C.c_int32), ('ctab', C.c_int64 * 8), ('atab', C.c_int64 * 8)]
 
 
 class GenieTrainOpts(C.Structure):

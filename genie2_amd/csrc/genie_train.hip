@@ -769,6 +769,12 @@ int genie_train_gemm(genie_stream_t stream, const genie_gemm_desc_t* q, const fl
     GemmP p{a, b, c, bias, q->M, q->N, q->K, q->am, q->ak, q->bk, q->bn, q->cm, q->cn, q->batch, q->nb2, q->a1, q->a2, q->b1, q->b2, q->c1, q->c2,
             q->nsplit, q->alpha, q->mode};
     p.relu = q->relu; p.gate = gate; p.asum = asum;
+    if (q->cblk > 0) {
+        const int64_t span = q->cblk_m ? q->M : q->N;
+        if (q->batch != 1 || gate || (span + q->cblk - 1) / q->cblk > 8) return -1;
+        p.cblk = q->cblk; p.cblk_m = q->cblk_m ? 1 : 0;
+        for (int t = 0; t < 8; ++t) { p.ctab[t] = q->ctab[t]; p.atab[t] = q->atab[t]; }
+    }
     launch_gemm(static_cast<hipStream_t>(stream), p, q->terms);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -553,7 +553,7 @@ void launch_gemm(hipStream_t st, const GemmP& p_in, int terms) {
             if (p.asum && (akc || p.batch != 1)) { launch_colsum(st, p.A, nullptr, p.K, p.M, p.asum, nullptr, p.ak); p.asum = nullptr; }
             static const bool nobig = getenv("GENIE_GEMM_NO_BIG") != nullptr;
             const long long big_tiles = (long long)(p.M / 128) * (p.N / 128) * p.batch * p.nsplit;
-            if (!nobig && p.M % 128 == 0 && p.N % 128 == 0 && big_tiles >= 256) {
+            if (!nobig && p.M % 128 == 0 && p.N % 128 == 0 && big_tiles >= 192) {
                 const dim3 gb(p.N / 128, p.M / 128, p.batch * p.nsplit);
                 if (terms <= 1) launch_gemm_big_t<1>(st, p, gb, akc, bkc);
                 else if (terms == 2) launch_gemm_big_t<2>(st, p, gb, akc, bkc);
@@ -586,6 +586,13 @@ void launch_gemm(hipStream_t st, const GemmP& p_in, int terms) {
 // split-K factor for a reduction of length K into `tiles` output tiles (x batch): enough work-groups to fill the chip, at least 128 of
 // K each.  Only for mode 2 (atomic accumulation).
 int gemm_splits(long long M, long long N, long long K, long long batch) {
+    // several 128 x 128 output tiles: one work-group of the 128-tile kernel per CU (its LDS admits one) -- the 64-tile kernel spends
+    // more vector-ALU time splitting its operand tiles into bf16 pieces than the matrix pipe spends on them (a 64 x 64 tile has half
+    // the MFMAs per split element), which is what a long-K weight gradient is bound by, not its bytes
+    if (batch == 1 && M % 128 == 0 && N % 128 == 0 && (M / 128) * (N / 128) >= 2 && (M / 128) * (N / 128) <= 32 && K >= 16384) {
+        const long long t = (M / 128) * (N / 128);
+        return (int)std::max<long long>(8, 256 / t / 8 * 8);
+    }
     const long long tiles = ((M + 63) / 64) * ((N + 63) / 64) * batch;
     long long s = (768 + tiles - 1) / tiles;
     const long long smax = (K + 127) / 128;

@@ -249,11 +249,16 @@ double genie_train_gemm_flop(genie_handle_t h);
  *   A at a + z1 a1 + z2 a2 + m am + k ak;  B at b + z1 b1 + z2 b2 + k bk + n bn;  C at c + z1 c1 + z2 c2 + m cm + n cn
  * mode 0 store (then optionally relu, and / or zero where gate <= 0, gate laid out like C), 1 add, 2 atomic add (required for
  * nsplit > 1 or batches sharing C).  terms: bf16 pieces per f32 operand (1 = bf16 products, 2 = 16 bits, 3 = f32-grade).
- * asum (optional, batch 1, am == 1, ak == M): asum[m] += sum_k A[m][k].  Returns 0, or -1 for an impossible shape. */
+ * asum (optional, batch 1, am == 1, ak == M): asum[m] += sum_k A[m][k].
+ * cblk > 0 (batch 1, at most 8 blocks): C is a row of separately placed blocks of cblk output rows (cblk_m = 1) or columns (0), block t
+ * at c + ctab[t] with (m, n) at local index m - t cblk resp. n - t cblk, its asum entries at asum + atab[t] + local m -- how several
+ * Linears sharing an input run as one GEMM (genie_train.hip lin_fwd_ln_cat / lin_bwd_w_ln_cat).  Returns 0, or -1 for an impossible shape. */
 typedef struct {
     int32_t M, N, K, batch, nb2, nsplit, mode, terms, relu;
     int64_t am, ak, bk, bn, cm, cn, a1, a2, b1, b2, c1, c2;
     float alpha;
+    int32_t cblk, cblk_m;
+    int64_t ctab[8], atab[8];
 } genie_gemm_desc_t;
 int genie_train_gemm(genie_stream_t stream, const genie_gemm_desc_t* desc, const float* a, const float* b, float* c, const float* bias,
                      const float* gate, float* asum);

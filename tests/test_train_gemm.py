@@ -146,3 +146,50 @@ def test_two_piece_split_and_bad_arguments():
     d = capi.GenieGemmDesc(M=M, N=N, K=K, batch=1, nb2=1, nsplit=4, mode=0, terms=3, relu=0, am=K, ak=1, bk=1, bn=K, cm=N, cn=1, alpha=1.0)
     p = lambda t: C.c_void_p(t.data_ptr())
     assert lib.genie_train_gemm(None, C.byref(d), p(a.cuda()), p(b.cuda()), p(c), None, None, None) == -1      # split-K needs atomic mode
+
+
+@pytest.mark.parametrize('case', ['fwd_640', 'wgrad_640', 'fwd_small', 'wgrad_small'])
+def test_c_in_separately_placed_blocks(case):
+    """Several Linears sharing an input as ONE GEMM: the product's column blocks (forward) or row blocks (weight gradients, split-K with
+    row sums) land at separate places -- the tiled kernels take the block table, other shapes fall back to one GEMM per block."""
+    capi, lib = _lib()
+    g = torch.Generator().manual_seed(11)
+    nb = 5
+    if case.startswith('fwd'):
+        R, K, O = (4096, 128, 128) if case == 'fwd_640' else (96, 24, 24)
+        x = torch.randn(R, K, generator=g); w = torch.randn(nb * O, K, generator=g); bias = torch.randn(nb * O, generator=g)
+        # results interleaved with gaps inside one buffer, in shuffled order
+        order = [3, 0, 4, 1, 2]
+        buf = torch.full((nb * R * O + 5 * 64,), float('nan'), device='cuda')
+        offs = [order[k] * (R * O + 64) for k in range(nb)]
+        d = capi.GenieGemmDesc(M=R, N=nb * O, K=K, batch=1, nb2=1, nsplit=1, mode=0, terms=3, relu=0, am=K, ak=1, bk=1, bn=K, cm=O, cn=1, alpha=1.0,
+                               cblk=O, cblk_m=0)
+        for k in range(nb): d.ctab[k] = offs[k]
+        p = lambda t: C.c_void_p(t.data_ptr())
+        assert lib.genie_train_gemm(None, C.byref(d), p(x.cuda()), p(w.cuda()), p(buf), p(bias.cuda()), None, None) == 0
+        torch.cuda.synchronize()
+        ref = x.double() @ w.double().t() + bias.double()
+        scale = (x.double().abs() @ w.double().abs().t()).clamp_min(1e-30)
+        for k in range(nb):
+            got = buf[offs[k]:offs[k] + R * O].view(R, O).cpu().double()
+            assert ((got - ref[:, k * O:(k + 1) * O]).abs() / scale[:, k * O:(k + 1) * O]).max().item() <= TOL[3]
+    else:
+        R, K, O = (8192, 128, 128) if case == 'wgrad_640' else (200, 24, 24)
+        dy = torch.randn(R, nb * O, generator=g); x = torch.randn(R, K, generator=g)
+        blob = torch.zeros(nb * (O * K + O) + 64, device='cuda')             # [w0 | b0 | w1 | b1 | ...] like a state_dict blob
+        woff = [k * (O * K + O) for k in range(nb)]; boff = [k * (O * K + O) + O * K for k in range(nb)]
+        nsplit = 16 if case == 'wgrad_640' else 2
+        d = capi.GenieGemmDesc(M=nb * O, N=K, K=R, batch=1, nb2=1, nsplit=nsplit, mode=2, terms=3, relu=0, am=1, ak=nb * O, bk=K, bn=1, cm=K, cn=1,
+                               alpha=1.0, cblk=O, cblk_m=1)
+        for k in range(nb): d.ctab[k] = woff[k]; d.atab[k] = boff[k]
+        p = lambda t: C.c_void_p(t.data_ptr())
+        assert lib.genie_train_gemm(None, C.byref(d), p(dy.cuda()), p(x.cuda()), p(blob), None, None, p(blob)) == 0
+        torch.cuda.synchronize()
+        ref = dy.double().t() @ x.double()
+        scale = (dy.double().abs().t() @ x.double().abs()).clamp_min(1e-30)
+        for k in range(nb):
+            got = blob[woff[k]:woff[k] + O * K].view(O, K).cpu().double()
+            assert ((got - ref[k * O:(k + 1) * O]).abs() / scale[k * O:(k + 1) * O]).max().item() <= 4 * TOL[3]
+            gb = blob[boff[k]:boff[k] + O].cpu().double()
+            rb = dy.double()[:, k * O:(k + 1) * O].sum(0)
+            assert ((gb - rb).abs() / dy.double()[:, k * O:(k + 1) * O].abs().sum(0)).max().item() <= 1e-5
