@@ -585,13 +585,16 @@ void launch_gemm(hipStream_t st, const GemmP& p_in, int terms) {
 }
 // split-K factor for a reduction of length K into `tiles` output tiles (x batch): enough work-groups to fill the chip, at least 128 of
 // K each.  Only for mode 2 (atomic accumulation).
+#ifndef GM_SPLIT_WGS
+#define GM_SPLIT_WGS 512      // work-groups of a multi-tile split-K GEMM: two per CU, so that one's operand staging runs under the other's MFMAs
+#endif
 int gemm_splits(long long M, long long N, long long K, long long batch) {
     // several 128 x 128 output tiles: one work-group of the 128-tile kernel per CU (its LDS admits one) -- the 64-tile kernel spends
     // more vector-ALU time splitting its operand tiles into bf16 pieces than the matrix pipe spends on them (a 64 x 64 tile has half
     // the MFMAs per split element), which is what a long-K weight gradient is bound by, not its bytes
     if (batch == 1 && M % 128 == 0 && N % 128 == 0 && (M / 128) * (N / 128) >= 2 && (M / 128) * (N / 128) <= 32 && K >= 16384) {
         const long long t = (M / 128) * (N / 128);
-        return (int)std::max<long long>(8, 256 / t / 8 * 8);
+        return (int)std::max<long long>(8, GM_SPLIT_WGS / t / 8 * 8);
     }
     const long long tiles = ((M + 63) / 64) * ((N + 63) / 64) * batch;
     long long s = (768 + tiles - 1) / tiles;

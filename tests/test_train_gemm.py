@@ -193,3 +193,4 @@ def test_c_in_separately_placed_blocks(case):
             gb = blob[boff[k]:boff[k] + O].cpu().double()
             rb = dy.double()[:, k * O:(k + 1) * O].sum(0)
             assert ((gb - rb).abs() / dy.double()[:, k * O:(k + 1) * O].abs().sum(0)).max().item() <= 1e-5
+
