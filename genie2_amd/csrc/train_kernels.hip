@@ -1132,22 +1132,76 @@ __global__ __launch_bounds__(IPA_NT) void k_ipa_bwd_q(IpaDims d, const float* __
         // accumulates heads wave, wave + 4, ... so that one LDS read of p feeds every head of the thread
         float* pt = red + 16;               // [64][cp + 1]
         const int jj = tid & 63, hg = tid >> 6;
-        for (int j0 = 0; j0 < N; j0 += 64) {
-#pragma unroll 8
-            for (int u = tid; u < 64 * cp; u += IPA_NT) {
-                const int r = u / cp, c = u - r * cp;
-                pt[r * (cp + 1) + c] = j0 + r < N ? p[((size_t)bi * N + j0 + r) * cp + c] : 0.f;
+        // cp = 128, at most 16 heads: the pair term <d o_pair[h], p[b,i,j,:]> on the matrix pipe -- per wave 16 keys at a time, A = d o_pair
+        // (heads as rows, padded to 16), B = the keys' pair rows straight from global memory (a lane's two float4 are the 8 channels of
+        // its B fragment), both split into three bf16 pieces (six v_mfma_f32_16x16x32_bf16 per product: f32-grade like the GEMMs);
+        // the result lands in dat, the v / v_pt terms are added below.  (As a per-thread loop over the 128 channels out of an LDS tile
+        // this term was the kernel's largest phase.)
+        const bool pair_mfma = cp == 128 && H <= 16;
+        if (pair_mfma) {
+            const int lane = tid & 63, wave = tid >> 6, m = lane & 15, g = lane >> 4;
+            auto split3 = [](const float (&x)[8], bf16x8& h, bf16x8& mm, bf16x8& l) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    h[e] = (__bf16)x[e];
+                    const float r1 = x[e] - (float)h[e];
+                    mm[e] = (__bf16)r1;
+                    l[e] = (__bf16)(r1 - (float)mm[e]);
+                }
+            };
+            for (int j0 = wave * 16; j0 < N; j0 += (IPA_NT / 64) * 16) {
+                const int j = min(j0 + m, N - 1);
+                const float* prow = p + ((size_t)bi * N + j) * cp + 8 * g;
+                float4 x0[4], x1[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) { x0[ks] = *reinterpret_cast<const float4*>(prow + ks * 32); x1[ks] = *reinterpret_cast<const float4*>(prow + ks * 32 + 4); }
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    float xa[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xa[e] = m < H ? sdop[m * cp + ks * 32 + 8 * g + e] : 0.f;
+                    const float xb[8] = {x0[ks].x, x0[ks].y, x0[ks].z, x0[ks].w, x1[ks].x, x1[ks].y, x1[ks].z, x1[ks].w};
+                    bf16x8 ah, am, al, bh, bm, bl;
+                    split3(xa, ah, am, al);
+                    split3(xb, bh, bm, bl);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+                }
+                if (j0 + m < N) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (4 * g + r < H) dat[(4 * g + r) * N + j0 + m] = acc[r];        // D row 4 g + r = head, column m = key
+                }
             }
             __syncthreads();
+        }
+        for (int j0 = 0; j0 < N; j0 += 64) {
+            if (!pair_mfma) {
+#pragma unroll 8
+                for (int u = tid; u < 64 * cp; u += IPA_NT) {
+                    const int r = u / cp, c = u - r * cp;
+                    pt[r * (cp + 1) + c] = j0 + r < N ? p[((size_t)bi * N + j0 + r) * cp + c] : 0.f;
+                }
+                __syncthreads();
+            }
             const int j = j0 + jj;
             if (j < N) {
                 float acc[4] = {0.f, 0.f, 0.f, 0.f};
                 const float* prow = pt + jj * (cp + 1);
-#pragma unroll 8
-                for (int c = 0; c < cp; ++c) {
-                    const float pv = prow[c];
+                if (pair_mfma) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) if (hg + (IPA_NT / 64) * t < H) acc[t] += sdop[(hg + (IPA_NT / 64) * t) * cp + c] * pv;
+                    for (int t = 0; t < 4; ++t) if (hg + (IPA_NT / 64) * t < H) acc[t] = dat[(hg + (IPA_NT / 64) * t) * N + j];
+                } else {
+#pragma unroll 8
+                    for (int c = 0; c < cp; ++c) {
+                        const float pv = prow[c];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) if (hg + (IPA_NT / 64) * t < H) acc[t] += sdop[(hg + (IPA_NT / 64) * t) * cp + c] * pv;
+                    }
                 }
                 const size_t mj = (size_t)b * N + j;
 #pragma unroll
@@ -1177,8 +1231,9 @@ __global__ __launch_bounds__(IPA_NT) void k_ipa_bwd_q(IpaDims d, const float* __
                     dat[h * N + j] = sacc;
                 }
             }
-            __syncthreads();
+            if (!pair_mfma) __syncthreads();
         }
+        if (pair_mfma) __syncthreads();
     }
     const float cpt = sqrtf(1.0f / (3.0f * ((float)Pq * 9.0f / 2.0f)));
     if (!(d.skip & 2)) {   // d logits = att (d att - sum_j att d att); d head_weights, d bias of linear_b
