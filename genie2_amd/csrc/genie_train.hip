@@ -174,10 +174,7 @@ struct Run {
         GemmP p{dY, Xhat, G + w, nullptr, O, K, (int)R, 1, lddy ? lddy : O, K, 1, K, 1, 1, 1, 0, 0, 0, 0, 0, 0, gemm_splits(O, K, R, 1), 1.0f, 2};
         p.asum = G + b_off;
         p.colscale = W + g_off;
-        gemm(p);
-        if (dry) return;
-        ProfScope ps_(h, st, KC_TR_EW);
-        launch_rank1_add(st, G + w, W + beta_off, G + b_off, O, K);
+        gemm(p);          // (the beta part, dW[o][k] += beta[k] db[o], is added for all such Linears at once at the end of the pass: launch_rank1_table)
     }
     // ... of `nb` Linears of O outputs each on the same xhat, their output gradients the column blocks of dYcat [R][nb O]: one GEMM
     // (xhat is read once), its row blocks landing on the nb weight gradients inside the blob
@@ -190,9 +187,6 @@ struct Run {
         p.cblk = O; p.cblk_m = 1;
         for (int k = 0; k < nb; ++k) { p.ctab[k] = (long long)w[k]; p.atab[k] = (long long)b_off[k]; }
         gemm(p);
-        if (dry) return;
-        ProfScope ps_(h, st, KC_TR_EW);
-        for (int k = 0; k < nb; ++k) launch_rank1_add(st, G + w[k], W + beta_off, G + b_off[k], O, K);
     }
     void ln_fwd(const float* x, size_t g, size_t b, float* y, float* xhat, float* rstd, long long R, int C) {
         if (dry) return;
@@ -270,30 +264,33 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
     // Every Linear of the pair stack that follows a LayerNorm runs on xhat with the LayerNorm's affine folded into its weights; all
     // 6 L x 2 + L folds in ONE launch here (the table of blob offsets depends on the dims only and is uploaded once per handle)
     std::vector<FoldEntry> fold_plan;
-    std::vector<size_t> fold_tri((size_t)L * 2 * 6), fold_tr(L);
+    std::vector<size_t> fold_tri((size_t)L * 2 * 7), fold_tr(L);
     size_t fold_floats = 0;
     {
         // (folded weights [O][K] at the returned offset, the folded bias right behind them)
         auto plan = [&](size_t w, size_t b, size_t g, size_t be, int Oo, int Kk) {
             fold_plan.push_back(FoldEntry{(long long)w, (long long)b, (long long)g, (long long)be, (long long)fold_floats,
-                                          (long long)(fold_floats + (size_t)Oo * Kk), Oo, Kk});
+                                          (long long)(fold_floats + (size_t)Oo * Kk), -1, Oo, Kk});
             const size_t at = fold_floats;
             fold_floats += ((size_t)Oo * Kk + Oo + 63) / 64 * 64;
             return at;
         };
-        // five Linears on the same input whose folded weights form ONE matrix [5 O][K] (then the five biases): they run as one GEMM
+        // five Linears on the same input whose folded weights form ONE matrix [5 O][K] (then the five biases, then the five unfolded
+        // matrices stacked the same way, f[6]: the B operand of their one input-gradient GEMM): they run as one GEMM
         auto plan5 = [&](const size_t (&w)[5], const size_t (&b)[5], size_t g, size_t be, int Oo, int Kk, size_t* f) {
+            const size_t raw0 = fold_floats + ((size_t)5 * Oo * Kk + 5 * Oo + 63) / 64 * 64;
             for (int k = 0; k < 5; ++k) {
                 f[k] = fold_floats + (size_t)k * Oo * Kk;
                 fold_plan.push_back(FoldEntry{(long long)w[k], (long long)b[k], (long long)g, (long long)be, (long long)f[k],
-                                              (long long)(fold_floats + (size_t)5 * Oo * Kk + (size_t)k * Oo), Oo, Kk});
+                                              (long long)(fold_floats + (size_t)5 * Oo * Kk + (size_t)k * Oo), (long long)(raw0 + (size_t)k * Oo * Kk), Oo, Kk});
             }
-            fold_floats += ((size_t)5 * Oo * Kk + 5 * Oo + 63) / 64 * 64;
+            f[6] = raw0;
+            fold_floats = raw0 + (size_t)5 * Oo * Kk;
         };
         for (int l = 0; l < L; ++l) {
             for (int dir = 0; dir < 2; ++dir) {
                 const TriOff& t = dir == 0 ? O.pair[l].out : O.pair[l].in;
-                size_t* f = &fold_tri[((size_t)l * 2 + dir) * 6];
+                size_t* f = &fold_tri[((size_t)l * 2 + dir) * 7];
                 if (ch == cp) {
                     const size_t w5[5] = {t.ap_w, t.ag_w, t.bp_w, t.bg_w, t.g_w}, b5[5] = {t.ap_b, t.ag_b, t.bp_b, t.bg_b, t.g_b};
                     plan5(w5, b5, t.lni_g, t.lni_b, ch, cp, f);
@@ -389,8 +386,8 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         T.off = mark;
     };
     for (int l = 0; l < L; ++l) {
-        tri_fwd(O.pair[l].out, ps[l].out, true, (uint32_t)(4 * l), &fold_tri[((size_t)l * 2) * 6]);
-        tri_fwd(O.pair[l].in, ps[l].in, false, (uint32_t)(4 * l + 1), &fold_tri[((size_t)l * 2 + 1) * 6]);
+        tri_fwd(O.pair[l].out, ps[l].out, true, (uint32_t)(4 * l), &fold_tri[((size_t)l * 2) * 7]);
+        tri_fwd(O.pair[l].in, ps[l].in, false, (uint32_t)(4 * l + 1), &fold_tri[((size_t)l * 2 + 1) * 7]);
         TransSave& s = ps[l].tr;
         const PairOff& o = O.pair[l];
         s.xhat = K.f(P * cp); s.rstd = K.f(P); s.h = K.f(P * nh);
@@ -552,7 +549,7 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
     }
     if (!dry && opt.struct_done_event) (void)hipEventRecord((hipEvent_t)opt.struct_done_event, st);      // structure_net.* gradients are final
     // ---- pair transform net, backwards.  dP = gradient wrt the pair representation leaving the current sub-layer.
-    auto tri_bwd = [&](const TriOff& t, TriSave& sv, bool outgoing, uint32_t tag) {
+    auto tri_bwd = [&](const TriOff& t, TriSave& sv, bool outgoing, uint32_t tag, const size_t* fo) {
         size_t mark = T.off;
         // ch == 128: the gradients of the five Linears on LN_in(z) are the column blocks [d ap | d ag | d bp | d bg | d g] of ONE row-major
         // matrix, so that their input gradients are one GEMM against the five weight matrices stacked (no read-modify-write of dzn)
@@ -603,9 +600,10 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         if (cmf) {              // a = ap m s, so  d ap = da m s  and  d ag = da a (1 - s): the projections themselves are not needed
             dap = dycat; dag = dycat + ch; dbp = dycat + 2 * ch; dbg = dycat + 3 * ch;
             if (!dry) { ProfScope ps_(h, st, KC_TR_TRANSPOSE); launch_gate_bwd_from_cm(st, dacm, dbcm, sv.acm, sv.bcm, sv.ag, sv.bg, rm, dap, dag, dbp, dbg, B, N, ch, ncat5); }
-            // the five weight matrices stacked [4 ch + cp][cp] (in the blob their biases sit between them)
-            float* wcat = T.f((size_t)ncat5 * cp);
-            if (!dry) {
+            // the five weight matrices stacked [4 ch + cp][cp] (in the blob their biases sit between them): with ch == cp the fold launch
+            // at the start of the pass has left that stack next to the folded weights
+            float* wcat = ch == cp ? (dry ? nullptr : foldbuf + fo[6]) : T.f((size_t)ncat5 * cp);
+            if (!dry && ch != cp) {
                 const size_t offs[5] = {t.ap_w, t.ag_w, t.bp_w, t.bg_w, t.g_w};
                 for (int k = 0; k < 5; ++k)
                     (void)hipMemcpyAsync(wcat + (size_t)k * ch * cp, Wd + offs[k], (size_t)(k < 4 ? ch : cp) * cp * 4, hipMemcpyDeviceToDevice, st);
@@ -666,8 +664,8 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         r.lin_bwd_x(dh, P, nh, o.w1, cp, dzn, cp, false);
         r.ln_bwd(dzn, sv.xhat, sv.rstd, o.ln_g, o.ln_b, dP, P, cp, true);
         T.off = mark;
-        tri_bwd(o.in, ps[l].in, false, (uint32_t)(4 * l + 1));
-        tri_bwd(o.out, ps[l].out, true, (uint32_t)(4 * l));
+        tri_bwd(o.in, ps[l].in, false, (uint32_t)(4 * l + 1), &fold_tri[((size_t)l * 2 + 1) * 7]);
+        tri_bwd(o.out, ps[l].out, true, (uint32_t)(4 * l), &fold_tri[((size_t)l * 2) * 7]);
     }
     // ---- pair feature net and single feature net
     {
@@ -696,6 +694,14 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         r.ew((long long)M * cs, [=] __device__(long long i) { ds[i] *= rm[i / cs]; });
         r.lin_bwd_w(ds, M, cs, xs, ldx, nsi, O.single_w, -1);
         T.off = mark;
+    }
+    // every weight gradient taken against a LayerNorm's xhat (lin_bwd_w_ln: exactly the Linears of the fold table) still lacks its beta
+    // part, dW[o][k] += beta[k] db[o]; the bias gradients are final now
+    if (!dry && Gd && !fold_plan.empty()) {
+        int max_ok = 0;
+        for (const FoldEntry& e : fold_plan) max_ok = std::max(max_ok, e.O * e.K);
+        ProfScope ps_(h, st, KC_TR_EW);
+        launch_rank1_table(st, Gd, Wd, h->train->fold_tab, (int)fold_plan.size(), max_ok);
     }
     if (kept_bytes) *kept_bytes = K.peak;
     if (tmp_bytes) *tmp_bytes = T.peak;

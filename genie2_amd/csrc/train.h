@@ -51,10 +51,13 @@ void launch_gate_bwd_from_cm(hipStream_t st, const float* dacm, const float* dbc
 //   Wf[o][k] = W[o][k] gamma[k],   bf[o] = b[o] + sum_k W[o][k] beta[k]          (b may be NULL)
 void launch_fold_ln(hipStream_t st, const float* W, const float* b, const float* gamma, const float* beta, float* Wf, float* bf, int O, int K);
 // ... for a table of Linears in one launch (all offsets into the weight blob `wts` / the scratch `dst`; b < 0: no bias)
-struct FoldEntry { long long w, b, g, beta, dst, bdst; int O, K; };       // Wf at dst, bf at bdst
+struct FoldEntry { long long w, b, g, beta, dst, bdst, raw; int O, K; };  // Wf at dst, bf at bdst; raw >= 0: W itself copied to dst-buffer + raw
+                                                                         // (the unfolded weights of several Linears stacked for one input-gradient GEMM)
 void launch_fold_ln_table(hipStream_t st, const float* wts, float* dst, const FoldEntry* table_dev, int n_entries, int max_O);
 // dW[o][c] += beta[c] db[o]   (the beta part of a weight gradient taken against xhat, see GemmP::colscale)
 void launch_rank1_add(hipStream_t st, float* dW, const float* beta, const float* db, int O, int C);
+// ... for every entry of a fold table in one launch, at the end of the backward pass:  grads[w + o K + k] += wts[beta + k] grads[b + o]
+void launch_rank1_table(hipStream_t st, float* grads, const float* wts, const FoldEntry* table_dev, int n_entries, int max_OK);
 void launch_pair_features(hipStream_t st, const float* trans, const float* rots, const int8_t* codes, const float* rmask, const uint8_t* fstm,
                           const uint8_t* fsm, const float* mpos, const int32_t* ridx, const int32_t* cidx, float* F, int B, int N, int nbin,
                           float dmin, float dstep, int relk);

@@ -225,9 +225,11 @@ __global__ __launch_bounds__(256) void k_fold_ln_table(const float* __restrict__
     const float* W = wts + e.w + (size_t)o * e.K;
     float* Wf = dst + e.dst + (size_t)o * e.K;
     float s = 0.f;
+    float* Wr = e.raw >= 0 ? dst + e.raw + (size_t)o * e.K : nullptr;
     for (int k = lane; k < e.K; k += 64) {
         const float w = W[k];
         Wf[k] = w * wts[e.g + k];
+        if (Wr) Wr[k] = w;
         s += w * wts[e.beta + k];
     }
 #pragma unroll
@@ -236,4 +238,13 @@ __global__ __launch_bounds__(256) void k_fold_ln_table(const float* __restrict__
 }
 void launch_fold_ln_table(hipStream_t st, const float* wts, float* dst, const FoldEntry* table_dev, int n_entries, int max_O) {
     if (n_entries > 0) hipLaunchKernelGGL(k_fold_ln_table, dim3((max_O + 3) / 4, n_entries), dim3(256), 0, st, wts, dst, table_dev);
+}
+
+__global__ __launch_bounds__(256) void k_rank1_table(float* __restrict__ grads, const float* __restrict__ wts, const FoldEntry* __restrict__ tab) {
+    const FoldEntry e = tab[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < e.O * e.K) grads[e.w + i] += wts[e.beta + i % e.K] * grads[e.b + i / e.K];
+}
+void launch_rank1_table(hipStream_t st, float* grads, const float* wts, const FoldEntry* table_dev, int n_entries, int max_OK) {
+    if (n_entries > 0) hipLaunchKernelGGL(k_rank1_table, dim3((max_OK + 255) / 256, n_entries), dim3(256), 0, st, grads, wts, table_dev);
 }
