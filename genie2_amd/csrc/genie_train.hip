@@ -374,6 +374,24 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         if (!cat5) r.lin_fwd_ln(s.xhat, P, cp, cp, s.g, fw(4));
         {
             float *u = s.u, *g = s.g;
+            if (cp % 4 == 0) {      // four channels of one pair row per thread: 16-byte accesses (five passes of the pair tensor, 83 -> 6x us)
+                r.ew(P * cp / 4, [=] __device__(long long e4) {
+                    const long long e = e4 * 4, row = e / cp; const int c = (int)(e % cp);
+                    const int j = (int)(row % N); const long long b = row / ((long long)N * N);
+                    float4 gv = *reinterpret_cast<const float4*>(g + e);
+                    const float4 uv = *reinterpret_cast<const float4*>(u + e);
+                    float4 zv = *reinterpret_cast<const float4*>(z + e);
+                    gv.x = 1.0f / (1.0f + expf(-gv.x)); gv.y = 1.0f / (1.0f + expf(-gv.y)); gv.z = 1.0f / (1.0f + expf(-gv.z)); gv.w = 1.0f / (1.0f + expf(-gv.w));
+                    *reinterpret_cast<float4*>(g + e) = gv;
+                    const uint64_t di = (uint64_t)((b * N + j) * cp + c);
+                    const bool dr = r_tri > 0.f;
+                    zv.x += uv.x * gv.x * (dr ? drop_scale(seed, tag, di, r_tri) : 1.0f);
+                    zv.y += uv.y * gv.y * (dr ? drop_scale(seed, tag, di + 1, r_tri) : 1.0f);
+                    zv.z += uv.z * gv.z * (dr ? drop_scale(seed, tag, di + 2, r_tri) : 1.0f);
+                    zv.w += uv.w * gv.w * (dr ? drop_scale(seed, tag, di + 3, r_tri) : 1.0f);
+                    *reinterpret_cast<float4*>(z + e) = zv;
+                });
+            } else
             r.ew(P * cp, [=] __device__(long long e) {
                 const float gg = 1.0f / (1.0f + expf(-g[e]));
                 g[e] = gg;
@@ -560,6 +578,20 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         const int ldg = cmf ? ncat5 : cp;
         {
             const float *u = sv.u, *g = sv.g;
+            if (cp % 4 == 0 && ldg % 4 == 0) {
+                r.ew(P * cp / 4, [=] __device__(long long e4) {
+                    const long long e = e4 * 4, row = e / cp; const int c = (int)(e % cp);
+                    const int j = (int)(row % N); const long long b = row / ((long long)N * N);
+                    const float4 dv = *reinterpret_cast<const float4*>(dP + e), uv = *reinterpret_cast<const float4*>(u + e), gv = *reinterpret_cast<const float4*>(g + e);
+                    const uint64_t di = (uint64_t)((b * N + j) * cp + c);
+                    const bool dr = r_tri > 0.f;
+                    const float4 dout = make_float4(dv.x * (dr ? drop_scale(seed, tag, di, r_tri) : 1.0f), dv.y * (dr ? drop_scale(seed, tag, di + 1, r_tri) : 1.0f),
+                                                    dv.z * (dr ? drop_scale(seed, tag, di + 2, r_tri) : 1.0f), dv.w * (dr ? drop_scale(seed, tag, di + 3, r_tri) : 1.0f));
+                    *reinterpret_cast<float4*>(du + e) = make_float4(dout.x * gv.x, dout.y * gv.y, dout.z * gv.z, dout.w * gv.w);
+                    *reinterpret_cast<float4*>(dgl + row * ldg + c) = make_float4(dout.x * uv.x * gv.x * (1.0f - gv.x), dout.y * uv.y * gv.y * (1.0f - gv.y),
+                                                                                  dout.z * uv.z * gv.z * (1.0f - gv.z), dout.w * uv.w * gv.w * (1.0f - gv.w));
+                });
+            } else
             r.ew(P * cp, [=] __device__(long long e) {
                 const long long row = e / cp; const int c = (int)(e % cp);
                 const int j = (int)(row % N); const long long b = row / ((long long)N * N);
