@@ -253,6 +253,17 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         r.lin_fwd(Fm, nf, P, kt, O.wt, -1, cp, z, 0);
         r.lin_fwd(Fm + kt, nf, P, km, O.wm, -1, cp, z, 1);
         r.lin_fwd(Fm + kt + km, nf, P, kr, O.wrel, -1, cp, z, 1);
+        if (cp % 4 == 0) {
+            r.ew(P * cp / 4, [=] __device__(long long e4) {
+                const long long e = e4 * 4, row = e / cp; const int c = (int)(e % cp);
+                const int j = (int)(row % N); const long long bi = row / N; const long long b = bi / N;
+                const float m = rm[bi] * rm[b * N + j];
+                float4 zv = *reinterpret_cast<const float4*>(z + e);
+                const float4 a = *reinterpret_cast<const float4*>(pi + bi * cp + c), bb = *reinterpret_cast<const float4*>(pj + (b * N + j) * cp + c);
+                zv.x = (zv.x + a.x + bb.x) * m; zv.y = (zv.y + a.y + bb.y) * m; zv.z = (zv.z + a.z + bb.z) * m; zv.w = (zv.w + a.w + bb.w) * m;
+                *reinterpret_cast<float4*>(z + e) = zv;
+            });
+        } else
         r.ew(P * cp, [=] __device__(long long e) {
             const long long row = e / cp; const int c = (int)(e % cp);
             const int j = (int)(row % N); const long long bi = row / N; const long long b = bi / N;
@@ -414,6 +425,16 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         r.ln_fwd(z, o.ln_g, o.ln_b, nullptr, s.xhat, s.rstd, P, cp);
         r.lin_fwd_ln(s.xhat, P, cp, nh, s.h, dry ? nullptr : foldbuf + fold_tr[l], true);          // LayerNorm's affine folded into Linear + ReLU
         r.lin_fwd(s.h, nh, P, nh, o.w2, o.b2, cp, ot);
+        if (cp % 4 == 0) {
+            r.ew(P * cp / 4, [=] __device__(long long e4) {
+                const long long e = e4 * 4, row = e / cp; const int j = (int)(row % N); const long long bi = row / N; const long long b = bi / N;
+                const float m = rm[bi] * rm[b * N + j];
+                float4 zv = *reinterpret_cast<const float4*>(z + e);
+                const float4 o4 = *reinterpret_cast<const float4*>(ot + e);
+                zv.x = (zv.x + o4.x * m) * m; zv.y = (zv.y + o4.y * m) * m; zv.z = (zv.z + o4.z * m) * m; zv.w = (zv.w + o4.w * m) * m;
+                *reinterpret_cast<float4*>(z + e) = zv;
+            });
+        } else
         r.ew(P * cp, [=] __device__(long long e) {
             const long long row = e / cp; const int j = (int)(row % N); const long long bi = row / N; const long long b = bi / N;
             const float m = rm[bi] * rm[b * N + j];
@@ -682,6 +703,16 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         size_t mark = T.off;
         // z_out = (z + o m) m:  dz = dP m (kept in dP);  do = dz m
         float* dot = T.f(P * cp);
+        if (cp % 4 == 0) {
+            r.ew(P * cp / 4, [=] __device__(long long e4) {
+                const long long e = e4 * 4, row = e / cp; const int j = (int)(row % N); const long long bi = row / N; const long long b = bi / N;
+                const float m = rm[bi] * rm[b * N + j];
+                float4 g = *reinterpret_cast<const float4*>(dP + e);
+                g.x *= m; g.y *= m; g.z *= m; g.w *= m;
+                *reinterpret_cast<float4*>(dP + e) = g;
+                *reinterpret_cast<float4*>(dot + e) = make_float4(g.x * m, g.y * m, g.z * m, g.w * m);
+            });
+        } else
         r.ew(P * cp, [=] __device__(long long e) {
             const long long row = e / cp; const int j = (int)(row % N); const long long bi = row / N; const long long b = bi / N;
             const float m = rm[bi] * rm[b * N + j];
@@ -702,6 +733,15 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
     // ---- pair feature net and single feature net
     {
         size_t mark = T.off;
+        if (cp % 4 == 0) {
+            r.ew(P * cp / 4, [=] __device__(long long e4) {
+                const long long e = e4 * 4, row = e / cp; const int j = (int)(row % N); const long long bi = row / N; const long long b = bi / N;
+                const float m = rm[bi] * rm[b * N + j];
+                float4 g = *reinterpret_cast<const float4*>(dP + e);
+                g.x *= m; g.y *= m; g.z *= m; g.w *= m;
+                *reinterpret_cast<float4*>(dP + e) = g;
+            });
+        } else
         r.ew(P * cp, [=] __device__(long long e) {
             const long long row = e / cp; const int j = (int)(row % N); const long long bi = row / N; const long long b = bi / N;
             dP[e] *= rm[bi] * rm[b * N + j];

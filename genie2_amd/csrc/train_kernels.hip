@@ -798,7 +798,27 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ a, con
         if (out_g) atomicAdd(out_g + c, sg);
     }
 }
+// ... C = 128 with no affine output wanted (the pair stack's LayerNorms keep xhat only): a row per half-wave of float4 lanes
+__global__ __launch_bounds__(256) void k_ln_fwd128(const float* __restrict__ x, float* __restrict__ xhat, float* __restrict__ rstd, long long R) {
+    constexpr int C = 128;
+    const int lane = threadIdx.x & 63, l32 = lane & 31;
+    const long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    if (row >= R) return;           // (a whole half-wave; the shuffles below stay inside it)
+    const float4 v = *reinterpret_cast<const float4*>(x + row * C + 4 * l32);
+    float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.0f / C);
+    const float4 dv = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+    float ss = (dv.x * dv.x + dv.y * dv.y) + (dv.z * dv.z + dv.w * dv.w);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float rs = 1.0f / sqrtf(ss * (1.0f / C) + GENIE_LN_EPS);
+    if (l32 == 0 && rstd) rstd[row] = rs;
+    *reinterpret_cast<float4*>(xhat + row * C + 4 * l32) = make_float4(dv.x * rs, dv.y * rs, dv.z * rs, dv.w * rs);
+}
 void launch_ln_fwd(hipStream_t st, const float* x, const float* g, const float* b, float* y, float* xhat, float* rstd, long long R, int C) {
+    if (C == 128 && !y && xhat && R >= 4096) { hipLaunchKernelGGL(k_ln_fwd128, dim3((unsigned)((R + 7) / 8)), dim3(256), 0, st, x, xhat, rstd, R); return; }
     hipLaunchKernelGGL(k_ln_fwd, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, x, g, b, y, xhat, rstd, R, C);
 }
 void launch_ln_bwd(hipStream_t st, const float* dy, const float* xhat, const float* rstd, const float* g, float* dx, long long R, int C, int accumulate,
