@@ -1794,8 +1794,8 @@ static size_t ipa_attn_t1_lds(const genie_dims_t& d, int N) {      // k_ipa_attn
 #define IPA_Q8 8             // queries per work-group of the 1024-thread matrix-pipe form
 static size_t ipa_attn_q_lds(const genie_dims_t& d, int N, bool mf = false, int Q = IPA_Q);
 static bool ipa_use_q8(const genie_dims_t& d, int N) {
-    static const bool on = getenv("GENIE_IPA_Q8") != nullptr;       // measured slower (80.5 vs 76.0 us per launch): opt-in
-    return on && ipa_attn_q_lds(d, N, true, IPA_Q8) <= 160 * 1024;
+    // measured slower (80.5 vs 76.0 us per launch): opt-in; read per call so that a test can compare both forms
+    return getenv("GENIE_IPA_Q8") != nullptr && ipa_attn_q_lds(d, N, true, IPA_Q8) <= 160 * 1024;
 }
 static bool ipa_use_q(const genie_dims_t& d, int N) { return ipa_attn_q_lds(d, N) <= 160 * 1024; }
 static size_t ipa_attn_t_lds(const genie_dims_t& d, int N) { return ipa_use_q(d, N) ? ipa_attn_q_lds(d, N) : ipa_attn_t1_lds(d, N); }

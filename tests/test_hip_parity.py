@@ -584,3 +584,33 @@ def test_two_stream_structure_net_is_bit_identical(base_engine, monkeypatch):
     for k in res[0]:
         assert torch.isfinite(res[0][k]).all(), k
         assert torch.equal(res[0][k], res[1][k]), k
+
+
+@pytest.mark.gpu
+def test_eight_query_attention_form_matches_the_default(base_engine, monkeypatch):
+    """GENIE_IPA_Q8 selects the attention kernel's 1024-thread form (eight queries per work-group, one head per wave in the a v / a v_pts
+    phase, no partial sums through LDS): same arithmetic in a different summation split, so the step's outputs must agree with the
+    four-query default to f32 rounding -- on a ragged batch whose last query group is partial for both forms."""
+    f = O.empty_features([250, 203, 117])
+    g = torch.Generator().manual_seed(21)
+    B, N = f['residue_mask'].shape
+    x = torch.randn(B, N, 3, generator=g) * 6
+    base_engine.set_math('hx')
+    base_engine.bind_features(f)
+    r = base_engine.frenet(x)
+    ts = torch.randint(1, 1001, (B,), generator=g).int()
+    taps = ('states', 'ipa_cat0', 'trans_out')
+    monkeypatch.delenv('GENIE_IPA_Q8', raising=False)
+    ref = base_engine.denoise(x, r, ts, None, taps=taps)
+    monkeypatch.setenv('GENIE_IPA_Q8', '1')
+    try:
+        out = base_engine.denoise(x, r, ts, None, taps=taps)
+    finally:
+        monkeypatch.delenv('GENIE_IPA_Q8', raising=False)
+    m = f['residue_mask'].float().to(ref['z'].device)
+    for k in ref:
+        assert torch.isfinite(out[k]).all(), k
+        w = m.reshape((1,) * (ref[k].dim() - 3) + (B, N, 1))                 # padded residues carry no meaning
+        scale = max(1.0, float((ref[k] * w).abs().max()))
+        d = float(((out[k] - ref[k]) * w).abs().max())
+        assert d <= 2e-5 * scale, (k, d, scale)
