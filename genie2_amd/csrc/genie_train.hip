@@ -77,7 +77,7 @@ struct Arena {
 };
 
 struct TriSave { float *xhat, *rstd, *ap, *ag, *bp, *bg, *acm, *bcm, *xhat_o, *rstd_o, *u, *g; };
-struct TransSave { float *xhat, *rstd, *h; };
+struct TransSave { float *xhat, *rstd, *h; unsigned* hmask; };     // hmask: sign pattern of h, one bit per element (null: not kept)
 struct PairSave { TriSave out, in; TransSave tr; };
 struct StructSave {
     float *s_in, *q, *kv, *qplin, *kvplin, *qp, *kp, *vp, *att, *cat, *xhat1, *rstd1, *s2, *h1, *h2, *xhat2, *rstd2, *s4, *bb, *R, *T;
@@ -135,9 +135,11 @@ struct Run {
     }
     // dX[R][K] (+)= dY[R][O] W[O][K]
     // `relu_out` (laid out like dX, not with accumulate): the forward ReLU's output -- dX is zeroed where it is not positive
-    void lin_bwd_x(const float* dY, long long R, int O, size_t w, int K, float* dX, long long lddx, bool accumulate, const float* relu_out = nullptr) {
+    void lin_bwd_x(const float* dY, long long R, int O, size_t w, int K, float* dX, long long lddx, bool accumulate, const float* relu_out = nullptr,
+                   const unsigned* relu_mask = nullptr) {
         GemmP p{dY, W + w, dX, nullptr, (int)R, K, O, O, 1, K, 1, lddx, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0f, accumulate ? 1 : 0};
-        p.gate = relu_out;
+        if (relu_mask) p.mask_in = relu_mask;       // (the forward output's sign pattern, GemmP::mask_in)
+        else p.gate = relu_out;
         gemm(p);
     }
     // dX[R][K] = dY[R][O] Wc[O][K] with the weight at a raw device pointer (a concatenation of several Linears' matrices)
@@ -154,9 +156,11 @@ struct Run {
     }
     // Y[R][O] = (xhat gamma + beta) W^T + b without forming xhat gamma + beta: the Linear's weights folded with the LayerNorm's affine
     // (`fold`: O K + O floats written by launch_fold_ln_table at the start of the pass) applied to xhat
-    void lin_fwd_ln(const float* Xhat, long long R, int K, int O, float* Y, const float* fold, bool relu = false, const float* fold_b = nullptr) {
+    void lin_fwd_ln(const float* Xhat, long long R, int K, int O, float* Y, const float* fold, bool relu = false, const float* fold_b = nullptr,
+                    unsigned* mask_out = nullptr) {
         GemmP p{Xhat, fold, Y, fold_b ? fold_b : fold ? fold + (size_t)O * K : nullptr, (int)R, O, K, K, 1, 1, K, O, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0f, 0};
         p.relu = relu ? 1 : 0;
+        p.mask_out = mask_out;
         gemm(p);
     }
     // ... `nb` of them on the same xhat in one GEMM (xhat is read once): folded weights stacked [nb O][K], biases [nb O]; result k to Y[k]
@@ -420,10 +424,17 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         TransSave& s = ps[l].tr;
         const PairOff& o = O.pair[l];
         s.xhat = K.f(P * cp); s.rstd = K.f(P); s.h = K.f(P * nh);
+        // where the 128-tile kernel runs both the Linear + ReLU and the ReLU's backward GEMM, the forward pass leaves h's sign pattern as
+        // one bit per element and the backward GEMM's epilogue reads that instead of h itself (268 MB per layer at N = 256, batch 2)
+        {
+            const GemmP gf{nullptr, nullptr, nullptr, nullptr, (int)P, nh, cp, cp, 1, 1, cp, nh, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0f, 0};       // lin_fwd_ln
+            const GemmP gb{nullptr, nullptr, nullptr, nullptr, (int)P, nh, cp, cp, 1, nh, 1, nh, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0f, 0};       // lin_bwd_x through w2
+            s.hmask = (nh % 32 == 0 && gemm_takes_mask(gf) && gemm_takes_mask(gb)) ? reinterpret_cast<unsigned*>(K.f(P * (nh / 32))) : nullptr;
+        }
         size_t mark = T.off;
         float* ot = T.f(P * cp);
         r.ln_fwd(z, o.ln_g, o.ln_b, nullptr, s.xhat, s.rstd, P, cp);
-        r.lin_fwd_ln(s.xhat, P, cp, nh, s.h, dry ? nullptr : foldbuf + fold_tr[l], true);          // LayerNorm's affine folded into Linear + ReLU
+        r.lin_fwd_ln(s.xhat, P, cp, nh, s.h, dry ? nullptr : foldbuf + fold_tr[l], true, nullptr, dry ? nullptr : s.hmask);          // LayerNorm's affine folded into Linear + ReLU
         r.lin_fwd(s.h, nh, P, nh, o.w2, o.b2, cp, ot);
         if (cp % 4 == 0) {
             r.ew(P * cp / 4, [=] __device__(long long e4) {
@@ -721,7 +732,7 @@ static int train_run(genie_ctx* h, hipStream_t st, bool dry, const float* Wd, fl
         });
         r.lin_bwd_w(dot, P, cp, sv.h, nh, nh, o.w2, (long long)o.b2);
         float* dh = T.f(P * nh);
-        r.lin_bwd_x(dot, P, cp, o.w2, nh, dh, nh, false, sv.h);          // through the ReLU
+        r.lin_bwd_x(dot, P, cp, o.w2, nh, dh, nh, false, sv.h, dry ? nullptr : sv.hmask);          // through the ReLU
         r.lin_bwd_w_ln(dh, P, nh, sv.xhat, cp, o.w1, o.b1, o.ln_g, o.ln_b);
         float* dzn = dot;
         r.lin_bwd_x(dh, P, nh, o.w1, cp, dzn, cp, false);

@@ -25,7 +25,12 @@ struct GemmP {
     int cblk, cblk_m;
     long long ctab[8], atab[8];
     int xcd;          // set by launch_gemm: split-K work-groups renumbered so that the tiles of one K range share an XCD (its L2)
+    // 128-tile kernel only (gemm_takes_mask), mode 0, batch 1, cm == N, cn == 1: one bit per element of C, word (m, n / 32) at [m N / 32 + n / 32]
+    //   mask_out: bit = (stored value > 0)            (a Linear + ReLU leaves its sign pattern: 1/32 of the bytes of its output)
+    //   mask_in:  store v where the bit is set, else 0  (ReLU backward on the dX GEMM without re-reading the forward output as `gate`)
+    unsigned* mask_out; const unsigned* mask_in;
 };
+bool gemm_takes_mask(const GemmP& p);      // launch_gemm would run this product on the 128-tile kernel
 void launch_gemm(hipStream_t st, const GemmP& p, int terms);
 int gemm_splits(long long M, long long N, long long K, long long batch);
 

@@ -483,12 +483,18 @@ __global__ __launch_bounds__(512, 4) void k_gemm_big(const GemmP p) {
         float* d0 = dbase + (long long)col * p.cn;
         if (p.mode == 0) {
             const float* g0 = p.gate ? p.gate + (d0 - p.C) : nullptr;
+            const long long mw = (long long)(m0 + wm * 32 + 4 * (lane >> 5)) * (p.N >> 5) + (col >> 5);      // mask word of this lane's first row
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long long o = (long long)((r & 3) + 8 * (r >> 2)) * p.cm;
                 float v = acc[r] * al + bv;
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (g0 && !(g0[o] > 0.f)) v = 0.f;
+                if (p.mask_in && !((p.mask_in[mw + (long long)((r & 3) + 8 * (r >> 2)) * (p.N >> 5)] >> (lane & 31)) & 1u)) v = 0.f;
+                if (p.mask_out) {         // lanes 0..31 hold one row, lanes 32..63 the row four below
+                    const unsigned long long bal = __ballot(v > 0.f);
+                    if ((lane & 31) == 0) p.mask_out[mw + (long long)((r & 3) + 8 * (r >> 2)) * (p.N >> 5)] = (unsigned)(lane ? bal >> 32 : bal);
+                }
                 d0[o] = v;
             }
         } else if (p.mode == 1) {
@@ -524,16 +530,29 @@ static void launch_gemm_t(hipStream_t st, const GemmP& p, dim3 grid, bool akc, b
     else hipLaunchKernelGGL((k_gemm<TERMS, false, false>), grid, dim3(256), 0, st, p, vecA, vecB, total);
 }
 // terms: bf16 pieces per operand -- 1: plain bf16 (one MFMA per product), 2: 16 significand bits (three MFMAs), 3: 24 bits (six)
+// which kernel launch_gemm runs a product on: 2 the 128-tile kernel, 1 the 64-tile kernel, 0 the generic one
+static int gemm_kernel_choice(const GemmP& p) {
+    const bool ua = p.ak == 1 || p.am == 1, ub = p.bk == 1 || p.bn == 1;
+    const long long ks = ((p.K + p.nsplit - 1) / p.nsplit + GM_BK - 1) / GM_BK * GM_BK;
+    const long long lim = 1LL << 24;              // a lane offset is at most 64 rows (or GM_BK k) of such a stride
+    static const bool off = getenv("GENIE_GEMM_GENERIC") != nullptr;
+    const bool fast = !off && ua && ub && p.M % 64 == 0 && p.N % 64 == 0 && p.K % GM_BK == 0 && ks % GM_BK == 0 && p.am < lim && p.ak < lim && p.bk < lim &&
+                      p.bn < lim && (long long)p.batch * p.nsplit < 65536 && p.M / 64 < 65536;
+    if (!fast) return 0;
+    static const bool nobig = getenv("GENIE_GEMM_NO_BIG") != nullptr;
+    const long long big_tiles = (long long)(p.M / 128) * (p.N / 128) * p.batch * p.nsplit;
+    const bool use_big = !nobig && p.M % 128 == 0 && p.N % 128 == 0 && (big_tiles >= 256 || (big_tiles >= 192 && (p.M / 128) * (p.N / 128) >= 2));
+    return use_big ? 2 : 1;
+}
+bool gemm_takes_mask(const GemmP& p) { return p.cblk == 0 && p.batch == 1 && p.mode == 0 && p.cn == 1 && p.cm == p.N && gemm_kernel_choice(p) == 2; }
+
 void launch_gemm(hipStream_t st, const GemmP& p_in, int terms) {
     GemmP p = p_in;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.batch <= 0) return;
+    if ((p.mask_in || p.mask_out) && !gemm_takes_mask(p)) { fprintf(stderr, "launch_gemm: mask_in / mask_out on a product the 128-tile kernel does not run\n"); abort(); }
     {   // the fast path
-        const bool ua = p.ak == 1 || p.am == 1, ub = p.bk == 1 || p.bn == 1;
-        const long long ks = ((p.K + p.nsplit - 1) / p.nsplit + GM_BK - 1) / GM_BK * GM_BK;
-        const long long lim = 1LL << 24;              // a lane offset is at most 64 rows (or GM_BK k) of such a stride
-        static const bool off = getenv("GENIE_GEMM_GENERIC") != nullptr;
-        const bool fast = !off && ua && ub && p.M % 64 == 0 && p.N % 64 == 0 && p.K % GM_BK == 0 && ks % GM_BK == 0 && p.am < lim && p.ak < lim && p.bk < lim &&
-                          p.bn < lim && (long long)p.batch * p.nsplit < 65536 && p.M / 64 < 65536;
+        const int choice = gemm_kernel_choice(p);
+        const bool fast = choice > 0;
         if (p.cblk > 0 && !(fast && p.cblk % 128 == 0 && !p.gate && p.batch == 1)) {
             // C in blocks is a property of the two tiled kernels: otherwise one GEMM per block
             const int nblk = ((p.cblk_m ? p.M : p.N) + p.cblk - 1) / p.cblk;
@@ -556,10 +575,7 @@ void launch_gemm(hipStream_t st, const GemmP& p_in, int terms) {
 
             const bool akc = p.ak == 1, bkc = p.bk == 1;
             if (p.asum && (akc || p.batch != 1)) { launch_colsum(st, p.A, nullptr, p.K, p.M, p.asum, nullptr, p.ak); p.asum = nullptr; }
-            static const bool nobig = getenv("GENIE_GEMM_NO_BIG") != nullptr;
-            const long long big_tiles = (long long)(p.M / 128) * (p.N / 128) * p.batch * p.nsplit;
-            const bool use_big = !nobig && p.M % 128 == 0 && p.N % 128 == 0 && (big_tiles >= 256 || (big_tiles >= 192 && (p.M / 128) * (p.N / 128) >= 2));
-            if (use_big) {
+            if (choice == 2) {
                 const dim3 gb(p.N / 128, p.M / 128, p.batch * p.nsplit);
                 if (terms <= 1) launch_gemm_big_t<1>(st, p, gb, akc, bkc);
                 else if (terms == 2) launch_gemm_big_t<2>(st, p, gb, akc, bkc);
