@@ -12,6 +12,37 @@ import torch
 from conftest import ROOT, load_golden
 
 
+def test_ctypes_mirrors_have_the_headers_struct_layout(tmp_path):
+    """The structs cross the C ABI by pointer: size and every field offset of the ctypes mirrors (genie2_amd/capi.py) against what a C
+    compiler makes of include/genie_hip.h."""
+    import ctypes as C
+    import subprocess
+    from genie2_amd import capi
+    pairs = {'genie_dims_t': capi.GenieDims, 'genie_features_t': capi.GenieFeatures, 'genie_taps_t': capi.GenieTaps,
+             'genie_train_opts_t': capi.GenieTrainOpts, 'genie_gemm_desc_t': capi.GenieGemmDesc}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "genie_hip.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    seen = 0
+    for ln in out.splitlines():
+        cname, what, val = ln.split()
+        cls = pairs[cname]
+        if what == 'size':
+            assert C.sizeof(cls) == int(val), (cname, C.sizeof(cls), val)
+        else:
+            assert getattr(cls, what).offset == int(val), (cname, what, getattr(cls, what).offset, val)
+        seen += 1
+    assert seen == sum(len(c._fields_) + 1 for c in pairs.values())
+
+
 def test_library_exports_every_declared_symbol():
     from genie2_amd import build, capi
     build.build()
